@@ -1,0 +1,115 @@
+/*
+ * tsta_engine.h — C-ABI of the MI355X-native alignment engine (libtsta_hip.so).
+ *
+ * Drop-in boundary for TSTA's SIMD hot path.  The reference has no library API: its hot path is reached
+ * through three `main()`s and a `void block_alignment(void* pack)` thread-pool task that communicates
+ * through process globals (psa/psa.c:113-137,365-433; msa/c-t-simd.c:26-34,602-657).  Each entry point
+ * below replaces one such region of the reference; the citation says which.  Plain C, plain pointers and
+ * sizes; no HIP, C++ or torch types.  Every function returns 0 (TSTA_OK) or a negative tsta_status and
+ * never calls exit() (the reference exit()s / crashes on errors, seqio.c:38,47,180; c-t-simd.c:154).
+ *
+ * Threading: one engine per host thread / per GPU.  An engine owns its device workspaces.
+ */
+#ifndef TSTA_ENGINE_H
+#define TSTA_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tsta_status {
+    TSTA_OK = 0,
+    TSTA_ERR_INVALID_ARG = -1,
+    TSTA_ERR_NO_DEVICE = -2,      /* no HIP device / extension cannot run: there is NO CPU fallback */
+    TSTA_ERR_HIP = -3,            /* a HIP runtime call failed; see tsta_last_error() */
+    TSTA_ERR_OOM = -4,
+    TSTA_ERR_UNSUPPORTED = -5,    /* input outside the supported domain (documented per function) */
+    TSTA_ERR_INTERNAL = -6
+} tsta_status;
+
+/* Scoring parameters = the reference's globals M, X, E, O (psa.c:114-117, msa.c:22-25).
+ * A gap of length k costs O + k*E. */
+typedef struct tsta_params {
+    int32_t M;   /* -M match,      default  2 */
+    int32_t X;   /* -X mismatch,   default -5 */
+    int32_t E;   /* -E gap extend, default -2 */
+    int32_t O;   /* -O gap open,   default -4 */
+} tsta_params;
+
+typedef struct tsta_engine tsta_engine;
+
+const char* tsta_strerror(int status);
+const char* tsta_last_error(const tsta_engine* eng);       /* text of the last failing HIP call */
+int  tsta_device_count(void);                              /* <0: tsta_status */
+int  tsta_engine_create(int device, tsta_engine** out);
+void tsta_engine_destroy(tsta_engine* eng);
+void tsta_free(void* p);                                   /* frees host buffers returned by this library */
+
+/* ------------------------------------------------------------------------------------------------
+ * PSA, score only  ==  TSTA_psa_notrace's fill: blockmatrix_init + the block-anti-diagonal wavefront of
+ * block_alignment/row() + the `ms` reduction (psa.c:219-232, 234-433, 593-639) for MANY independent pairs.
+ * out[k] = the value the reference prints as `maxsorce` (psa.c:666) = max(-100, max_{i,j>=1} H(i,j)).
+ * The longer sequence of a pair becomes the column sequence (psa.c:194-199).
+ *
+ * seqs: concatenated sequence bytes (any byte values; compared for equality, case-sensitive, psa.c:253).
+ * off1/len1, off2/len2: start offset and length of the -1 / -2 sequence of each pair.
+ * Exactness domain: |H| must fit int32 (always true for lengths < 2^24 and |params| <= 127).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Host-pointer form (copies in, runs, copies out, synchronises). */
+int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                         int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                         const int64_t* off2, const int32_t* len2, int32_t* out);
+
+/* Device-pointer form: every pointer is a device pointer on the engine's device; asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the engine's own stream).  max_len = upper bound on every
+ * sequence length in the batch (sizes the per-wave boundary-row workspace). */
+int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs,
+                             const int64_t* d_off1, const int32_t* d_len1, const int64_t* d_off2,
+                             const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PSA with traceback  ==  TSTA_psa: fill with back/eback/fback (psa.c:294-327,358-362) + trace()
+ * (psa.c:435-518) for one pair.  Returns the printed maxsorce and the two gapped rows exactly as the
+ * reference writes them after ">1\n" and "\n>2\n" (psa.c:512-516): row_a belongs to the LONGER input.
+ * row_a/row_b are malloc'd, NUL-terminated, length *out_len; free with tsta_free().
+ * The packed trace matrix (1 byte per DP cell) lives in HBM only.
+ * ------------------------------------------------------------------------------------------------ */
+int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint8_t* s1, int64_t l1,
+                   const uint8_t* s2, int64_t l2, int32_t* maxscore, char** row_a, char** row_b,
+                   int64_t* out_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * POA fill  ==  one control() wavefront of TSTA_msa without node_fuse (c-t-simd.c:979-1045 driving
+ * block_alignment :602-657 / block_line_alignment :165-599): aligns `seq` (length n, 'N'-free) to a DAG
+ * given in topological order (p->sort[], topo.c:243-260) as CSR predecessor lists (order of poa::pre[]).
+ * Outputs (host pointers, any may be NULL):
+ *   source/esource/fsource : int8 [n_nodes][n] row-major, the reference's trace codes
+ *                            (c-t-simd.c:485-506, 530-538, 521-522/564-565) in plain (un-striped) layout
+ *   lastscore              : int32 [n_nodes], H(r, n)  (the reference keeps it for sinks: c-t-simd.c:577-578)
+ *   best_sink              : sink with the highest lastscore, ties -> lowest index (c-t-simd.c:737-750)
+ * Domain: every node has < 42 predecessors (poa.h:109 / trace code space).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct tsta_dag_csr {
+    int32_t        n_nodes;
+    const int32_t* pred_off;    /* n_nodes + 1 */
+    const int32_t* pred;        /* pred_off[n_nodes] entries, each < its node's index */
+    const uint8_t* base;        /* n_nodes */
+    const uint8_t* is_sink;     /* n_nodes (out == 0) */
+} tsta_dag_csr;
+
+int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
+                  int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
+                  int32_t* best_sink);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): duration of the kernels of the last *_dev / host call, measured with HIP
+ * events on the stream they ran on, and the number of kernel launches it took.
+ * ------------------------------------------------------------------------------------------------ */
+int tsta_last_kernel_ms(tsta_engine* eng, float* ms, int32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSTA_ENGINE_H */

@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every symbol
+include/tsta_engine.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import tsta_amd
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    tsta_amd.build()
+    return ctypes.CDLL(tsta_amd.lib_path)
+
+
+def header_symbols():
+    with open(os.path.join(util.ROOT, "include", "tsta_engine.h")) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsta_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_listed():
+    assert header_symbols() == sorted(tsta_amd.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_header_symbol(built_lib):
+    for s in header_symbols():
+        assert hasattr(built_lib, s), s
+
+
+def test_strerror_and_no_cpu_fallback(built_lib):
+    L = tsta_amd.lib()
+    assert L.tsta_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.tsta_strerror(-2)
+    import torch
+    if not torch.cuda.is_available():
+        # without a GPU the product path must fail loudly, not fall back to any CPU code
+        with pytest.raises(tsta_amd.TstaError):
+            tsta_amd.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    # the oracle is test infrastructure: nothing under tsta_amd/ or include/ may reference it
+    for root in ("tsta_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(util.ROOT, root)):
+            for fn in files:
+                if fn.endswith((".py", ".h", ".hip", ".c", ".cpp")) or fn == "Makefile":
+                    with open(os.path.join(dp, fn), errors="ignore") as f:
+                        body = f.read()
+                    assert "liboracle" not in body and "oracle/" not in body and "oracle_psa" not in body, (dp, fn)

@@ -1,0 +1,194 @@
+"""tsta_amd — MI355X-native drop-in for TSTA's alignment hot path.
+
+Thin ctypes binding over the C-ABI shared library ``tsta_amd/lib/libtsta_hip.so`` (include/tsta_engine.h).
+The product is the HIP library; this module only marshals numpy arrays / device pointers into it.  There is NO
+CPU fallback: if the library is missing or no gfx950 device is usable, calls raise ``TstaError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["TstaError", "Params", "Engine", "lib", "lib_path", "build", "EXPORTED_SYMBOLS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "lib", "libtsta_hip.so")
+
+# every symbol include/tsta_engine.h declares
+EXPORTED_SYMBOLS = [
+    "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
+    "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
+    "tsta_last_kernel_ms",
+]
+
+
+class TstaError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """Scoring parameters: the reference's globals M, X, E, O (psa.c:114-117)."""
+    _fields_ = [("M", C.c_int32), ("X", C.c_int32), ("E", C.c_int32), ("O", C.c_int32)]
+
+    def __init__(self, M=2, X=-5, E=-2, O=-4):
+        super().__init__(M, X, E, O)
+
+
+class DagCsr(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("pred_off", C.c_void_p), ("pred", C.c_void_p),
+                ("base", C.c_void_p), ("is_sink", C.c_void_p)]
+
+
+def build(verbose=False):
+    """Compile libtsta_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return lib_path
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (raises TstaError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise TstaError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C tsta_amd/csrc`); there is no CPU fallback" % lib_path)
+        L = C.CDLL(lib_path)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        L.tsta_strerror.restype = C.c_char_p; L.tsta_strerror.argtypes = [C.c_int]
+        L.tsta_last_error.restype = C.c_char_p; L.tsta_last_error.argtypes = [vp]
+        L.tsta_device_count.restype = C.c_int; L.tsta_device_count.argtypes = []
+        L.tsta_engine_create.restype = C.c_int; L.tsta_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.tsta_engine_destroy.restype = None; L.tsta_engine_destroy.argtypes = [vp]
+        L.tsta_free.restype = None; L.tsta_free.argtypes = [vp]
+        L.tsta_psa_score_batch.restype = C.c_int
+        L.tsta_psa_score_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
+        L.tsta_psa_score_batch_dev.restype = C.c_int
+        L.tsta_psa_score_batch_dev.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.tsta_psa_align.restype = C.c_int
+        L.tsta_psa_align.argtypes = [vp, C.POINTER(Params), vp, i64, vp, i64, C.POINTER(i32), C.POINTER(vp),
+                                     C.POINTER(vp), C.POINTER(i64)]
+        L.tsta_poa_fill.restype = C.c_int
+        L.tsta_poa_fill.argtypes = [vp, C.POINTER(Params), C.POINTER(DagCsr), vp, i32, vp, vp, vp, vp, C.POINTER(i32)]
+        L.tsta_last_kernel_ms.restype = C.c_int
+        L.tsta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_pairs(pairs):
+    """[(s1, s2), ...] of uint8 arrays / bytes -> (seqs, off1, len1, off2, len2) numpy arrays for the batch ABI."""
+    flat, o1, l1, o2, l2 = [], [], [], [], []
+    pos = 0
+    for a, b in pairs:
+        a = np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else np.asarray(a, dtype=np.uint8)
+        b = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else np.asarray(b, dtype=np.uint8)
+        o1.append(pos); l1.append(len(a)); flat.append(a); pos += len(a)
+        o2.append(pos); l2.append(len(b)); flat.append(b); pos += len(b)
+    seqs = np.concatenate(flat) if pos else np.zeros(0, dtype=np.uint8)
+    return (np.ascontiguousarray(seqs), np.array(o1, dtype=np.int64), np.array(l1, dtype=np.int32),
+            np.array(o2, dtype=np.int64), np.array(l2, dtype=np.int32))
+
+
+class Engine:
+    """One engine per GPU / host thread (mirrors ``tsta_engine`` of include/tsta_engine.h)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().tsta_engine_create(int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise TstaError("tsta_engine_create(device=%d): %s" % (device, lib().tsta_strerror(rc).decode()))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().tsta_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise TstaError("%s: %s (%s)" % (what, lib().tsta_strerror(rc).decode(),
+                                             lib().tsta_last_error(self._h).decode()))
+
+    # ---- PSA score-only batch (TSTA_psa_notrace fill for many pairs) ------------------------------
+    def psa_score_batch(self, pairs, params=None):
+        """pairs: list of (s1, s2) in CLI order (-1, -2).  Returns int32 array of `maxsorce` (psa.c:666)."""
+        params = params or Params()
+        seqs, o1, l1, o2, l2 = pack_pairs(pairs)
+        out = np.zeros(len(pairs), dtype=np.int32)
+        if len(pairs) == 0:
+            return out
+        sq = seqs if len(seqs) else np.zeros(1, dtype=np.uint8)
+        rc = lib().tsta_psa_score_batch(self._h, C.byref(params), len(pairs), _ptr(sq), len(seqs), _ptr(o1), _ptr(l1),
+                                        _ptr(o2), _ptr(l2), _ptr(out))
+        self._check(rc, "tsta_psa_score_batch")
+        return out
+
+    def psa_score_batch_dev(self, params, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream=0):
+        """Device-pointer form; arguments are integer device addresses (e.g. torch ``tensor.data_ptr()``),
+        `stream` a hipStream_t handle (torch: ``torch.cuda.current_stream().cuda_stream``).  Asynchronous."""
+        rc = lib().tsta_psa_score_batch_dev(self._h, C.byref(params), int(n_pairs), d_seqs, d_off1, d_len1, d_off2,
+                                            d_len2, d_out, int(max_len), C.c_void_p(stream or None))
+        self._check(rc, "tsta_psa_score_batch_dev")
+
+    # ---- PSA with traceback (TSTA_psa) --------------------------------------------------------------
+    def psa_align(self, s1, s2, params=None):
+        """-> (maxsorce, row_a, row_b): the two gapped rows as TSTA_psa writes them (row_a = longer input)."""
+        params = params or Params()
+        s1 = np.ascontiguousarray(np.frombuffer(s1, dtype=np.uint8) if isinstance(s1, (bytes, bytearray)) else s1,
+                                  dtype=np.uint8)
+        s2 = np.ascontiguousarray(np.frombuffer(s2, dtype=np.uint8) if isinstance(s2, (bytes, bytearray)) else s2,
+                                  dtype=np.uint8)
+        ms, ra, rb, ln = C.c_int32(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        p1 = s1 if len(s1) else np.zeros(1, dtype=np.uint8)
+        p2 = s2 if len(s2) else np.zeros(1, dtype=np.uint8)
+        rc = lib().tsta_psa_align(self._h, C.byref(params), _ptr(p1), len(s1), _ptr(p2), len(s2), C.byref(ms),
+                                  C.byref(ra), C.byref(rb), C.byref(ln))
+        self._check(rc, "tsta_psa_align")
+        a = C.string_at(ra, ln.value); b = C.string_at(rb, ln.value)
+        lib().tsta_free(ra); lib().tsta_free(rb)
+        return int(ms.value), a, b
+
+    # ---- POA fill (one control() wavefront of TSTA_msa) ---------------------------------------------
+    def poa_fill(self, pred_off, pred, base, is_sink, seq, params=None, want_trace=True):
+        """-> (best_sink, lastscore[V], source, esource, fsource) with int8 [V][n] trace arrays (or None)."""
+        params = params or Params()
+        pred_off = np.ascontiguousarray(pred_off, dtype=np.int32)
+        pred = np.ascontiguousarray(pred if len(pred) else np.zeros(1), dtype=np.int32)
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        is_sink = np.ascontiguousarray(is_sink, dtype=np.uint8)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        V, n = len(base), len(seq)
+        dag = DagCsr(V, _ptr(pred_off).value, _ptr(pred).value, _ptr(base).value, _ptr(is_sink).value)
+        last = np.zeros(V, dtype=np.int32)
+        best = C.c_int32(-1)
+        src = es = fs = None
+        if want_trace:
+            src = np.zeros((V, n), dtype=np.int8); es = np.zeros((V, n), dtype=np.int8); fs = np.zeros((V, n), dtype=np.int8)
+        rc = lib().tsta_poa_fill(self._h, C.byref(params), C.byref(dag), _ptr(seq), n,
+                                 _ptr(src) if want_trace else None, _ptr(es) if want_trace else None,
+                                 _ptr(fs) if want_trace else None, _ptr(last), C.byref(best))
+        self._check(rc, "tsta_poa_fill")
+        return int(best.value), last, src, es, fs
+
+    def last_kernel_ms(self):
+        ms, nl = C.c_float(), C.c_int32()
+        self._check(lib().tsta_last_kernel_ms(self._h, C.byref(ms), C.byref(nl)), "tsta_last_kernel_ms")
+        return float(ms.value), int(nl.value)

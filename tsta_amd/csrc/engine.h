@@ -1,0 +1,40 @@
+// engine.h — the object behind the opaque `tsta_engine*` of include/tsta_engine.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tsta {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Engine {
+    int         device = 0;
+    int         n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    hipStream_t timing_stream = nullptr;
+    bool        timing_valid = false;
+    int         n_launches = 0;
+    char        err[512] = {0};
+
+    DevBuf counter;      // ticket counters / flags (zeroed per launch)
+    DevBuf rows;         // PSA per-wave boundary rows
+    DevBuf in_seqs;      // staging for host-pointer entry points
+    DevBuf in_meta;
+    DevBuf out_scores;
+    DevBuf trace;        // packed trace matrix (tsta_psa_align) / POA trace arrays
+    DevBuf scratch;
+    DevBuf scratch2;
+
+    void set_error(const char* fmt, ...);
+    int  check(hipError_t e, const char* what);
+    int  reserve(DevBuf& b, size_t bytes, const char* what);
+    void timing_begin(hipStream_t s);
+    void timing_end(hipStream_t s);
+};
+
+}  // namespace tsta

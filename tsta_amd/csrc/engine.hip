@@ -1,0 +1,156 @@
+// engine.hip — C-ABI (include/tsta_engine.h) over the HIP kernels.  Host side of libtsta_hip.so.
+// No CPU fallback anywhere: without a usable gfx950 device every entry point fails with TSTA_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/tsta_engine.h"
+#include "engine.h"
+#include "kernels.h"
+
+namespace tsta {
+
+void Engine::set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, sizeof(err), fmt, ap);
+    va_end(ap);
+}
+
+int Engine::check(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return TSTA_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? TSTA_ERR_OOM : TSTA_ERR_HIP;
+}
+
+int Engine::reserve(DevBuf& b, size_t bytes, const char* what)
+{
+    if (b.bytes >= bytes && b.p) return TSTA_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    int rc = check(hipMalloc(&b.p, want), what);
+    if (rc != TSTA_OK) { b.p = nullptr; return rc; }
+    b.bytes = want;
+    return TSTA_OK;
+}
+
+void Engine::timing_begin(hipStream_t s) { timing_stream = s; n_launches = 0; (void)hipEventRecord(ev0, s); }
+void Engine::timing_end(hipStream_t s) { (void)hipEventRecord(ev1, s); timing_valid = true; }
+
+}  // namespace tsta
+
+using tsta::Engine;
+
+extern "C" {
+
+const char* tsta_strerror(int status)
+{
+    switch (status) {
+        case TSTA_OK: return "ok";
+        case TSTA_ERR_INVALID_ARG: return "invalid argument";
+        case TSTA_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case TSTA_ERR_HIP: return "HIP runtime error";
+        case TSTA_ERR_OOM: return "out of device memory";
+        case TSTA_ERR_UNSUPPORTED: return "input outside the supported domain";
+        case TSTA_ERR_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+const char* tsta_last_error(const tsta_engine* eng)
+{
+    return eng ? reinterpret_cast<const Engine*>(eng)->err : "";
+}
+
+int tsta_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return TSTA_ERR_NO_DEVICE; }
+    return n;
+}
+
+int tsta_engine_create(int device, tsta_engine** out)
+{
+    if (!out) return TSTA_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = tsta_device_count();
+    if (n <= 0) return TSTA_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return TSTA_ERR_INVALID_ARG;
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return TSTA_ERR_OOM;
+    e->device = device;
+    int rc;
+    hipDeviceProp_t prop;
+    if ((rc = e->check(hipSetDevice(device), "hipSetDevice")) != TSTA_OK ||
+        (rc = e->check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) != TSTA_OK) {
+        delete e; return rc;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {       // code objects are gfx950-only
+        delete e; return TSTA_ERR_NO_DEVICE;
+    }
+    e->n_cu = prop.multiProcessorCount;
+    if ((rc = e->check(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate")) != TSTA_OK ||
+        (rc = e->check(hipEventCreate(&e->ev0), "hipEventCreate")) != TSTA_OK ||
+        (rc = e->check(hipEventCreate(&e->ev1), "hipEventCreate")) != TSTA_OK ||
+        (rc = e->reserve(e->counter, 256, "hipMalloc(counter)")) != TSTA_OK) {
+        tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e)); return rc;
+    }
+    // hardware contract check: DPP whole-wave shifts behave as wave_ops.h assumes
+    int* d = reinterpret_cast<int*>(e->counter.p);
+    tsta::launch_dpp_selftest(d, e->stream);
+    int h[128];
+    if ((rc = e->check(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, e->stream), "selftest copy")) != TSTA_OK ||
+        (rc = e->check(hipStreamSynchronize(e->stream), "selftest sync")) != TSTA_OK) {
+        tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e)); return rc;
+    }
+    for (int l = 0; l < 64; ++l) {
+        const int ea = l == 0 ? 1000 : l - 1, eb = l == 63 ? 2063 : l + 1;
+        if (h[l] != ea || h[64 + l] != eb) {
+            e->set_error("DPP wave shift self-test failed at lane %d", l);
+            tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e));
+            return TSTA_ERR_INTERNAL;
+        }
+    }
+    *out = reinterpret_cast<tsta_engine*>(e);
+    return TSTA_OK;
+}
+
+void tsta_engine_destroy(tsta_engine* eng)
+{
+    if (!eng) return;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
+                            &e->scratch2}) {
+        if (b->p) (void)hipFree(b->p);
+    }
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+void tsta_free(void* p) { free(p); }
+
+int tsta_last_kernel_ms(tsta_engine* eng, float* ms, int32_t* n_launches)
+{
+    if (!eng || !ms) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    if (!e->timing_valid) return TSTA_ERR_INVALID_ARG;
+    int rc = e->check(hipEventSynchronize(e->ev1), "hipEventSynchronize");
+    if (rc != TSTA_OK) return rc;
+    rc = e->check(hipEventElapsedTime(ms, e->ev0, e->ev1), "hipEventElapsedTime");
+    if (n_launches) *n_launches = e->n_launches;
+    return rc;
+}
+
+}  // extern "C"
