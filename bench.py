@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — GCUPS of batched 50 kbp x 50 kbp global affine-gap alignment (score only) on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run, one rank
+per GPU.  A "step" = one pass of the hot path (tsta_psa_score_batch_dev through the C-ABI) over this rank's shard
+of the batch, inputs already resident in HBM, followed (N>1) by the RCCL all-gather of the int32 scores — the only
+collective on the path.  Workload = BASELINE.json config #5 per-GPU shard (independent pairs, weak scaling):
+PAIRS_PER_GPU pairs of LEN x LEN random DNA per GPU, default scoring (M=2 X=-5 E=-2 O=-4).
+
+Rank 0 prints ONE JSON line with `roofline` (HBM, algorithmic bytes; plus the VALU roofline that
+actually bounds this integer recurrence) and `cpu_baseline` (the reference's own AVX512+pthreadpool binary from
+oracle/_ref timed on this host's cores on a bounded sample; falls back to the scalar oracle port).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import tsta_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 int32 lane-ops/s
+VALU_OPS_PER_CELL = 10                # K1: E,F adds (2) cmp+cndmask+add (3) max3 (1) H+O (1) Ebar,Fbar (2) running max (1)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-gpu", type=int, default=int(os.environ.get("TSTA_BENCH_PAIRS", 8192)))
+    ap.add_argument("--len", type=int, default=50_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    return ap.parse_args()
+
+
+def make_shard(n_pairs, length, seed, device):
+    """Synthetic iid uniform ACGT, generated on the GPU (inputs are HBM-resident before the timed region)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    idx = torch.randint(0, 4, (2 * n_pairs * length,), generator=g, device=device, dtype=torch.uint8)
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    seqs = alpha[idx.long()] if idx.numel() < (1 << 28) else torch.cat(
+        [alpha[c.long()] for c in idx.split(1 << 28)])
+    del idx
+    k = torch.arange(n_pairs, device=device, dtype=torch.int64)
+    off1 = 2 * k * length
+    off2 = off1 + length
+    ln = torch.full((n_pairs,), length, dtype=torch.int32, device=device)
+    return seqs, off1, ln, off2, ln.clone()
+
+
+def cpu_baseline(length, sample_pairs, seed=12345):
+    """TSTA's own CPU path on this host: oracle/_ref/TSTA_psa_notrace (AVX512 + pthreadpool, -T = all cores),
+    one process per pair as the CLI is (psa.c:539-668).  Bounded sample of the same workload."""
+    from tests import util
+    try:
+        cores = len(os.sched_getaffinity(0))          # the cores this process may actually use
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    binary = os.path.join(util.REF_DIR, "TSTA_psa_notrace")
+    use_ref = os.path.exists(binary) and util.cpu_has("avx512bw")
+    if not use_ref:
+        alt = os.path.join(util.REF_DIR, "TSTA_psa_notrace_avx2")
+        if os.path.exists(alt) and util.cpu_has("avx2"):
+            binary, use_ref = alt, True
+    pairs = [(util.random_dna(seed + 2 * i, length), util.random_dna(seed + 2 * i + 1, length))
+             for i in range(max(1, sample_pairs))]
+    cells = float(len(pairs)) * length * length
+    if use_ref:
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                files = []
+                for i, (a, b) in enumerate(pairs):
+                    fa, fb = os.path.join(td, "a%d.fa" % i), os.path.join(td, "b%d.fa" % i)
+                    util.write_fasta(fa, "a", a); util.write_fasta(fb, "b", b)
+                    files.append((fa, fb))
+                subprocess.run([binary, "-T", str(cores), "-1", files[0][0], "-2", files[0][1]], capture_output=True,
+                               check=True, timeout=600)     # warm-up (page in the binary)
+                # repeat the sample until about TARGET_S seconds of CPU work have been timed (bounded)
+                t0 = time.perf_counter()
+                done = 0
+                while True:
+                    for fa, fb in files:
+                        r = subprocess.run([binary, "-T", str(cores), "-1", fa, "-2", fb], capture_output=True,
+                                           check=True, timeout=600)
+                        assert b"maxsorce=" in r.stdout
+                    done += len(files)
+                    dt = time.perf_counter() - t0
+                    if dt >= 12.0 or done >= 4096:
+                        break
+                cells = float(done) * length * length
+                pairs = pairs * (done // len(files))
+            return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "reference",
+                    "sample": "%d pairs of %dx%d random DNA, oracle/_ref/%s -T %d, one process per pair, %.1f s"
+                              % (len(pairs), length, length, os.path.basename(binary), cores, dt)}
+        except Exception as ex:      # binary cannot run on this host: fall through to the port
+            sys.stderr.write("cpu_baseline: reference binary failed (%r); using the oracle port\n" % (ex,))
+    pairs = pairs[:max(1, min(len(pairs), cores))]
+    cells = float(len(pairs)) * length * length
+    t0 = time.perf_counter()
+    util.oracle_maxscore_batch(pairs, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "%d pairs of %dx%d random DNA, scalar oracle, OpenMP over pairs, %.1f s" % (len(pairs), length, length, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    P, L = args.pairs_per_gpu, args.len
+    eng = tsta_amd.Engine(local_rank)
+    params = tsta_amd.Params()
+    seqs, off1, len1, off2, len2 = make_shard(P, L, 1000 + rank, dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    gathered = torch.empty(P * world, dtype=torch.int32, device=dev) if world > 1 else None
+    tstream = torch.cuda.Stream(device=dev)          # explicit stream: kernel, events and RCCL all ride on it
+    stream = tstream.cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        eng.psa_score_batch_dev(params, P, seqs.data_ptr(), off1.data_ptr(), len1.data_ptr(), off2.data_ptr(),
+                                len2.data_ptr(), scores.data_ptr(), L, stream)
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, scores)      # the path's only collective: final score gather
+
+    torch.cuda.synchronize()
+    with torch.cuda.stream(tstream):
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity on the result of the last step: random DNA gives a degenerate maxsorce in a tiny range
+    sc = scores.cpu().numpy()
+    assert sc.min() >= -100 and sc.max() < 2 * L, (sc.min(), sc.max())
+
+    if rank == 0:
+        cells_per_step = float(P) * world * L * L
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+        alg_bytes = float(P) * (2 * L + 4)                      # (len_a+len_b) B in + 4 B out per pair
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_psa_score.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            if tj.get("pairs_per_gpu") == P and tj.get("len") == L:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "GCUPS (DP cells/s) for batched 50kbp global affine-gap alignment",
+            "value": cells_per_step * args.steps / dt / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / max(1, args.steps) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE config #5 per-GPU shard: %d pairs/GPU of %d x %d random DNA, affine gap "
+                                   "M=2 X=-5 E=-2 O=-4, score only (maxsorce), inputs HBM-resident" % (P, L, L),
+                       "pairs_per_gpu": P, "len": L, "parallelism": "pairs sharded x%d, RCCL all-gather of scores" % world},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "psa_score_batch_kernel", "kernel_ms": kern_ms,
+                         "note": "integer max-plus recurrence: VALU-issue-bound, HBM fraction is ~0 by construction "
+                                 "(SURVEY 8d); see valu_roofline"},
+            "valu_roofline": {"ops_per_cell": VALU_OPS_PER_CELL,
+                              "achieved": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / 1e12,
+                              "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
+                              "frac": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            n_s = args.cpu_sample_pairs or min(256, max(4, int(round(16 * (50_000.0 / L) ** 2))))
+            out["cpu_baseline"] = cpu_baseline(L, n_s)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,15 +12,18 @@ using tsta::Engine;
 
 namespace tsta {
 
-static int psa_rows_per_lane()
+// Rows per lane (band height = 64*R).  Larger R amortises the per-step lane hand-off over more cells but
+// leaves lanes idle when the row sequence is shorter than a band.
+static int psa_rows_per_lane(int32_t max_len)
 {
-    static int r = 0;
-    if (r == 0) {
-        const char* s = getenv("TSTA_PSA_R");        // tuning knob for experiments; 4, 8 or 16
-        int v = s ? atoi(s) : 8;
-        r = (v == 4 || v == 16) ? v : 8;
+    static int forced = -1;
+    if (forced < 0) {
+        const char* s = getenv("TSTA_PSA_R");        // tuning knob for experiments: 4, 8 or 16
+        int v = s ? atoi(s) : 0;
+        forced = (v == 4 || v == 8 || v == 16) ? v : 0;
     }
-    return r;
+    if (forced) return forced;
+    return max_len >= 4096 ? 16 : (max_len >= 1024 ? 8 : 4);
 }
 
 }  // namespace tsta
@@ -40,7 +43,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     if (rc != TSTA_OK) return rc;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
 
-    const int R = tsta::psa_rows_per_lane();
+    const int R = tsta::psa_rows_per_lane(max_len);
     const int per_cu = tsta::psa_score_blocks_per_cu(R);
     int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, (int64_t)e->n_cu * per_cu);
     if (blocks < 1) blocks = 1;
