@@ -36,6 +36,9 @@ typedef struct oracle_params {
 int32_t oracle_psa_maxscore(const uint8_t* s1, int64_t l1, const uint8_t* s2, int64_t l2,
                             const oracle_params* p);
 
+void oracle_psa_scores(const uint8_t* s1, int64_t l1, const uint8_t* s2, int64_t l2, const oracle_params* p,
+                       int32_t* maxscore, int32_t* end_score);      /* + H(m,n), O(n) memory */
+
 /* Batch of independent pairs (OpenMP over pairs when threads > 1).  seqs = concatenated bytes,
  * off1/off2 = start offsets, len1/len2 = lengths. */
 void oracle_psa_maxscore_batch(int64_t n_pairs, const uint8_t* seqs, const int64_t* off1,

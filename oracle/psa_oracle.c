@@ -69,6 +69,15 @@ int32_t oracle_psa_maxscore(const uint8_t* s1, int64_t l1, const uint8_t* s2, in
     return fill_score(a, n, b, m, p, NULL);
 }
 
+/* maxsorce and the global end score H(m,n) in one O(n)-memory pass */
+void oracle_psa_scores(const uint8_t* s1, int64_t l1, const uint8_t* s2, int64_t l2, const oracle_params* p,
+                       int32_t* maxscore, int32_t* end_score)
+{
+    const uint8_t *a, *b; int64_t n, m;
+    orient(s1, l1, s2, l2, &a, &n, &b, &m);
+    *maxscore = fill_score(a, n, b, m, p, end_score);
+}
+
 void oracle_psa_maxscore_batch(int64_t n_pairs, const uint8_t* seqs, const int64_t* off1,
                                const int32_t* len1, const int64_t* off2, const int32_t* len2,
                                const oracle_params* p, int32_t* out, int threads)

@@ -101,6 +101,9 @@ def oracle():
         lib = C.CDLL(build_oracle())
         lib.oracle_psa_maxscore.restype = C.c_int32
         lib.oracle_psa_maxscore.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(OracleParams)]
+        lib.oracle_psa_scores.restype = None
+        lib.oracle_psa_scores.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(OracleParams),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.oracle_psa_maxscore_batch.restype = None
         lib.oracle_psa_maxscore_batch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.POINTER(OracleParams), C.c_void_p, C.c_int]
@@ -127,6 +130,28 @@ def oracle_maxscore(s1, s2, M=2, X=-5, E=-2, O=-4):
     s1 = np.ascontiguousarray(s1, dtype=np.uint8); s2 = np.ascontiguousarray(s2, dtype=np.uint8)
     p = OracleParams(M, X, E, O)
     return int(oracle().oracle_psa_maxscore(_ptr(s1), len(s1), _ptr(s2), len(s2), C.byref(p)))
+
+
+def oracle_scores(s1, s2, M=2, X=-5, E=-2, O=-4):
+    """-> (maxsorce, H(m,n)) in O(n) memory."""
+    s1 = np.ascontiguousarray(s1, dtype=np.uint8); s2 = np.ascontiguousarray(s2, dtype=np.uint8)
+    p = OracleParams(M, X, E, O); ms, es = C.c_int32(), C.c_int32()
+    oracle().oracle_psa_scores(_ptr(s1), len(s1), _ptr(s2), len(s2), C.byref(p), C.byref(ms), C.byref(es))
+    return int(ms.value), int(es.value)
+
+
+def alignment_score(row_a, row_b, M=2, X=-5, E=-2, O=-4):
+    """Affine score of a gapped alignment (two equal-length byte strings with '-')."""
+    a = np.frombuffer(row_a, dtype=np.uint8); b = np.frombuffer(row_b, dtype=np.uint8)
+    ga = a == ord("-"); gb = b == ord("-")
+    assert not np.any(ga & gb)
+    both = ~ga & ~gb
+    score = int(np.sum(np.where(a[both] == b[both], M, X)))
+    for g in (ga, gb):
+        ext = int(np.sum(g))
+        opens = int(np.sum(g[1:] & ~g[:-1])) + int(g[0]) if len(g) else 0
+        score += ext * E + opens * O
+    return score
 
 
 def oracle_maxscore_batch(pairs, M=2, X=-5, E=-2, O=-4, threads=8):
