@@ -1,0 +1,80 @@
+"""GPU parity: K4 (poa_fill_kernel) through tsta_poa_fill vs dumps of the compiled reference (every trace byte /
+sha256, sinks' lastsorce, best sink) and vs the oracle on synthetic DAGs with many predecessors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import tsta_amd
+from tests import util
+from tests.test_poa_oracle_golden import FIXTURES, check_against_fixture, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = tsta_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[4:-4] for p in FIXTURES])
+def test_reference_dumps(eng, path):
+    z, sc = load(path)
+    best, last, src, es, fs = eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"],
+                                           tsta_amd.Params(**sc))
+    check_against_fixture(z, best, last, src, es, fs)
+
+
+def random_dag(seed, V, max_pred, n):
+    """A random DAG in topological order (predecessors anywhere earlier, several sources/sinks) + a sequence."""
+    r = util.splitmix64(seed, 4 * V + 8)
+    base = np.frombuffer(b"ACGT", np.uint8)[(r[:V] >> np.uint64(62)).astype(np.int64)]
+    pred_off = [0]; pred = []
+    has_succ = np.zeros(V, bool)
+    for v in range(V):
+        k = int(r[V + v] % np.uint64(max_pred + 1)) if v > 0 else 0
+        if v > 0 and int(r[2 * V + v] % np.uint64(10)) != 0:
+            k = max(k, 1)                      # mostly connected; ~10% extra sources
+        k = min(k, v)
+        ps = set()
+        if k >= 1:
+            ps.add(v - 1)                      # chain edge first, like a POA backbone
+        q = util.splitmix64(seed * 7919 + v, max(1, k))
+        for x in range(k):
+            if len(ps) >= k:
+                break
+            ps.add(int(q[x] % np.uint64(v)))
+        ps = sorted(ps, reverse=True)          # arbitrary but fixed order of pre[]
+        for pidx in ps:
+            has_succ[pidx] = True
+        pred.extend(ps); pred_off.append(len(pred))
+    is_sink = (~has_succ).astype(np.uint8)
+    seq = util.random_dna(seed + 1, n)
+    return np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq
+
+
+@pytest.mark.parametrize("seed,V,max_pred,n", [(1, 50, 3, 40), (2, 300, 8, 1), (3, 64, 41, 700), (4, 1000, 5, 9),
+                                               (5, 700, 12, 8193), (6, 1, 0, 100), (7, 400, 2, 1025)])
+def test_random_dags_vs_oracle(eng, seed, V, max_pred, n):
+    pred_off, pred, base, is_sink, seq = random_dag(seed, V, max_pred, n)
+    for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0)):
+        got = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc))
+        want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq, **sc)
+        assert got[0] == want[0]
+        assert np.array_equal(got[1], want[1])
+        for g, w in zip(got[2:], want[2:]):
+            assert np.array_equal(g, w)
+
+
+def test_rejects_bad_dags(eng):
+    base = np.frombuffer(b"ACG", np.uint8); sink = np.array([0, 0, 1], np.uint8); seq = util.random_dna(1, 10)
+    with pytest.raises(tsta_amd.TstaError):       # predecessor not earlier in topological order
+        eng.poa_fill([0, 0, 1, 2], [2, 1], base, sink, seq)
+    V = 50
+    pred_off = [0] + [0] * 43 + [43] * (V - 43)   # node 43 has 43 predecessors (>= 42: outside the trace code space)
+    with pytest.raises(tsta_amd.TstaError):
+        eng.poa_fill(np.array(pred_off, np.int32), np.arange(43, dtype=np.int32), util.random_dna(2, V),
+                     np.ones(V, np.uint8), seq)
