@@ -26,6 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import tsta_amd  # noqa: E402
+from tsta_amd.sharding import gather_scores  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 int32 lane-ops/s
@@ -135,7 +136,7 @@ def main():
     params = tsta_amd.Params()
     seqs, off1, len1, off2, len2 = make_shard(P, L, 1000 + rank, dev)
     scores = torch.empty(P, dtype=torch.int32, device=dev)
-    gathered = torch.empty(P * world, dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = [None]
     tstream = torch.cuda.Stream(device=dev)          # explicit stream: kernel, events and RCCL all ride on it
     stream = tstream.cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -148,7 +149,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, scores)      # the path's only collective: final score gather
+            gathered[0] = gather_scores(scores, P * world)     # the path's only collective: final score gather
 
     torch.cuda.synchronize()
     with torch.cuda.stream(tstream):
