@@ -30,7 +30,7 @@ from tsta_amd.sharding import gather_scores  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 int32 lane-ops/s
-VALU_OPS_PER_CELL = 10                # K1: E,F adds (2) cmp+cndmask+add (3) max3 (1) H+O (1) Ebar,Fbar (2) running max (1)
+VALU_OPS_PER_CELL = 6.53              # K1p hot loop: 209 VALU instructions per 32 cells (6 v_pk_max/min + 6 add/sub/xor per 2 cells + 8 DPP + moves per step)
 
 
 def parse():
@@ -192,13 +192,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / max(1, args.steps) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "u16 packed x2 (biased, int32 per-pair base)", "data": "synthetic",
             "config": {"workload": "BASELINE config #5 per-GPU shard: %d pairs/GPU of %d x %d random DNA, affine gap "
                                    "M=2 X=-5 E=-2 O=-4, score only (maxsorce), inputs HBM-resident" % (P, L, L),
                        "pairs_per_gpu": P, "len": L, "parallelism": "pairs sharded x%d, RCCL all-gather of scores" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "psa_score_batch_kernel", "kernel_ms": kern_ms,
+                         "kernel": "psa_score_packed_kernel", "kernel_ms": kern_ms,
                          "note": "integer max-plus recurrence: VALU-issue-bound, HBM fraction is ~0 by construction "
                                  "(SURVEY 8d); see valu_roofline"},
             "valu_roofline": {"ops_per_cell": VALU_OPS_PER_CELL,

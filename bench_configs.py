@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""bench_configs.py — secondary measurements for BASELINE.json configs #2, #3, #4 (bench.py carries the headline
+metric / config #5 shard).  One JSON line per config; kernel time from HIP events inside the library."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import tsta_amd  # noqa: E402
+from bench import make_shard  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def config2(eng, reps=5):
+    P, L = 1024, 5000
+    dev = torch.device("cuda", 0)
+    seqs, off1, len1, off2, len2 = make_shard(P, L, 77, dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    prm = tsta_amd.Params()
+    ms = []
+    with torch.cuda.stream(st):
+        for i in range(reps + 1):
+            eng.psa_score_batch_dev(prm, P, seqs.data_ptr(), off1.data_ptr(), len1.data_ptr(), off2.data_ptr(),
+                                    len2.data_ptr(), scores.data_ptr(), L, st.cuda_stream)
+            k, _ = eng.last_kernel_ms()
+            if i:
+                ms.append(k)
+    t = float(np.median(ms))
+    return {"config": "#2: 1024 pairs 5 kbp x 5 kbp, score only", "kernel_ms": t, "gcups": P * L * L / t / 1e6,
+            "valu_frac_at_10ops": P * L * L * 10 / (t * 1e-3) / 7.86432e13}
+
+
+def config3(eng):
+    x = util.random_dna(777, 100_000); y = util.mutate(x, 778, 0.05)
+    eng.psa_align(x[:3000], y[:3000])                       # warm-up (allocations are per-size, this only pages code in)
+    t0 = time.perf_counter()
+    ms, ra, rb = eng.psa_align(x, y)
+    wall = time.perf_counter() - t0
+    k, nl = eng.last_kernel_ms()
+    cells = float(len(x)) * len(y)
+    t0 = time.perf_counter()
+    ms2, ra2, rb2 = eng.psa_align(x, y)                     # second call: workspaces already allocated
+    wall2 = time.perf_counter() - t0
+    k2, _ = eng.last_kernel_ms()
+    assert (ms, ra, rb) == (ms2, ra2, rb2)
+    return {"config": "#3: one 100 kbp x ~100 kbp pair with traceback (1 B/cell packed trace in HBM)",
+            "maxsorce": ms, "alignment_len": len(ra), "kernel_ms_first": k, "kernel_ms": k2, "launches": nl,
+            "wall_ms_first": wall * 1e3, "wall_ms": wall2 * 1e3, "gcups_kernel": cells / k2 / 1e6,
+            "gcups_wall": cells / wall2 / 1e9, "trace_bytes": cells,
+            "trace_write_GBs": cells / (k2 * 1e-3) / 1e9}
+
+
+def config4(eng):
+    out = []
+    tot_cells, tot_k, tot_wall = 0.0, 0.0, 0.0
+    for step in range(1, 5):
+        z = np.load(os.path.join(util.GOLDEN_DIR, "poa_readme_step%d.npz" % step))
+        args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+        eng.poa_fill(*args)                                 # warm-up / allocations
+        t0 = time.perf_counter()
+        best, last, src, es, fs = eng.poa_fill(*args)
+        wall = time.perf_counter() - t0
+        k, _ = eng.last_kernel_ms()
+        cells = float(len(z["base"])) * len(z["seq"])
+        tot_cells += cells; tot_k += k; tot_wall += wall
+        out.append({"step": step, "nodes": int(len(z["base"])), "kernel_ms": k, "wall_ms_with_trace_d2h": wall * 1e3,
+                    "best_lastsorce": int(last[best])})
+    return {"config": "#4: TSTA_msa README example, 4 POA fills (5 x 5 kbp)", "steps": out,
+            "kernel_ms_total": tot_k, "gcups_kernel": tot_cells / tot_k / 1e6, "wall_ms_total": tot_wall * 1e3}
+
+
+if __name__ == "__main__":
+    eng = tsta_amd.Engine(0)
+    which = sys.argv[1:] or ["2", "3", "4"]
+    if "2" in which:
+        print(json.dumps(config2(eng)), flush=True)
+    if "3" in which:
+        print(json.dumps(config3(eng)), flush=True)
+    if "4" in which:
+        print(json.dumps(config4(eng)), flush=True)
+    eng.close()

@@ -100,3 +100,62 @@ def test_full_size_property_identical_pairs(eng):
     assert got[0] == 2 * 50_000
     assert got[1] == util.oracle_maxscore(x, y)
     assert got[2] == util.oracle_maxscore(y, x)
+
+
+def _fixed_len(seq, n, seed):
+    seq = np.asarray(seq, dtype=np.uint8)
+    if len(seq) >= n:
+        return seq[:n]
+    return np.concatenate([seq, util.random_dna(seed, n - len(seq))])
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4),          # packed R=16
+                                     dict(M=10, X=-10, E=-3, O=-12),        # packed R=8 (range bound)
+                                     dict(M=1, X=-1, E=-1, O=0),
+                                     dict(M=5, X=-250, E=-1, O=-3),         # M-X = 255: edge of the packed select
+                                     dict(M=100, X=-100, E=-30, O=-60),     # too wide for 16-bit lanes: int32 path
+                                     dict(M=2, X=3, E=-2, O=-4)])           # X > M: int32 path
+def test_packed_couples_equal_geometry(eng, scoring):
+    # adjacent pairs with identical (n, m) are scored two-per-wave in packed 16-bit lanes (psa_score_packed.hip);
+    # results must be identical to the int32 path / oracle, including related sequences with large positive scores
+    pairs = []
+    for i, (n, m) in enumerate([(64, 64), (65, 1), (1, 1), (700, 70), (1024, 1024), (1025, 1023), (2048, 2047),
+                                (3000, 3000), (5000, 4096), (4097, 129)]):
+        for j in range(2):                                           # the two members of the couple differ in content
+            a = util.random_dna(9000 + 10 * i + j, n)
+            kind = (i + j) % 3
+            if kind == 0:
+                b = _fixed_len(util.mutate(a, 9500 + 10 * i + j, 0.06), m, 77 + i)      # related
+            elif kind == 1:
+                b = util.random_dna(9700 + 10 * i + j, m)                                # unrelated
+            else:
+                b = _fixed_len(a[::-1].copy(), m, 5)                                      # reversed: poor alignment
+            pairs.append((a, b) if j == 0 else (b, a))                                    # second member swapped
+    got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+    want = util.oracle_maxscore_batch(pairs, **scoring)
+    assert np.array_equal(got, want), (scoring, got.tolist(), want.tolist())
+
+
+def test_packed_adversarial_content(eng):
+    n = 6000
+    A = np.full(n, ord("A"), np.uint8); C = np.full(n, ord("C"), np.uint8)
+    x = util.random_dna(31, n)
+    lc = util.low_complexity(32, n, 2)
+    pairs = [(A, A.copy()), (A, C),                 # all-match diagonal / all-mismatch
+             (x, x.copy()), (x, x[::-1].copy()),
+             (lc, lc.copy()), (lc, np.roll(lc, 1)),
+             (np.concatenate([x[:3000], A[:3000]]), np.concatenate([A[:3000], x[:3000]])),   # long forced gaps
+             (x, np.concatenate([x[3000:], x[:3000]]))]
+    for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7)):
+        got = eng.psa_score_batch(pairs, tsta_amd.Params(**sc))
+        want = util.oracle_maxscore_batch(pairs, **sc)
+        assert np.array_equal(got, want), (sc, got.tolist(), want.tolist())
+
+
+def test_packed_and_int32_paths_agree_at_50k(eng, monkeypatch):
+    # full BASELINE length: related 50 kbp couples, packed path vs oracle (O(n) memory)
+    x = util.random_dna(4242, 50_000)
+    y = _fixed_len(util.mutate(x, 4243, 0.05), 50_000, 1)
+    z = _fixed_len(util.mutate(x, 4244, 0.15), 50_000, 2)
+    got = eng.psa_score_batch([(x, y), (x, z)])
+    assert got[0] == util.oracle_maxscore(x, y) and got[1] == util.oracle_maxscore(x, z)

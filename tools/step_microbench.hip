@@ -1,0 +1,104 @@
+// step_microbench.hip — runs the REAL per-step code of the score kernels (pstep / psa_step) on synthetic register
+// state at 1..8 waves per SIMD and reports cycles per step per SIMD.  Diagnostic tool, not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include "../tsta_amd/csrc/psa_score_packed.hip"
+#include "../tsta_amd/csrc/psa_score.hip"
+
+using namespace tsta;
+
+template <int R, int VARIANT>
+__global__ __launch_bounds__(256) void k_pstep(unsigned long long* out, const unsigned* init, int iters,
+                                               unsigned pe, unsigned po, unsigned pm, unsigned pmx)
+{
+    const int lane = threadIdx.x & 63;
+    PLane<R> s;
+    for (int k = 0; k < R; ++k) { s.hm[k] = init[lane + 64 * k]; s.fb[k] = init[lane + 64 * (k + R)]; s.bch[k] = init[lane + 64 * (k + 2 * R)] & 0xff00ff00u; }
+    s.hdm = init[lane]; s.hbot = init[lane + 1]; s.ebot = init[lane + 2]; s.cch = 0; s.th = init[lane + 3]; s.te = init[lane + 4];
+    s.ach = init[lane + 5] & 0xff00ff00u; s.sh = 0; s.se = 0; s.mx = 0;
+    pe = in_vgpr(pe); po = in_vgpr(po); pm = in_vgpr(pm); pmx = in_vgpr(pmx);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        if (VARIANT == 0) pstep<R, false, false>(s, i, lane, 1 << 30, R, pe, po, pm, pmx);
+        else {
+            // no cross-lane traffic: isolates the DPP cost
+            unsigned d = s.hdm, h = 0, eu = s.ebot;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const unsigned e = eu - pe, f = s.fb[k] - pe, x = s.cch ^ s.bch[k];
+                const unsigned tt = pkmin(x, pmx), dg = d - tt;
+                h = pkmax(pkmax(dg, e), f);
+                const unsigned g = h - po;
+                const unsigned eb = pkmax(e, g), fbn = pkmax(f, g);
+                d = s.hm[k]; s.hm[k] = h + pm; s.fb[k] = fbn; s.mx = pkmax(s.mx, h); eu = eb;
+            }
+            s.hbot = h; s.ebot = eu; s.hdm = h + pm; s.cch += 0x01000100u;
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned acc = s.mx ^ s.hbot ^ s.ebot ^ s.sh ^ s.se;
+    for (int k = 0; k < R; ++k) acc ^= s.hm[k] ^ s.fb[k];
+    if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (acc == 0x12345678u) out[0] = 0;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_istep(unsigned long long* out, const unsigned* init, int iters, int M, int X, int E, int O)
+{
+    const int lane = threadIdx.x & 63;
+    LaneState<R> s;
+    for (int k = 0; k < R; ++k) { s.hl[k] = init[lane + 64 * k]; s.fb[k] = init[lane + 64 * (k + R)]; s.bch[k] = init[lane + 64 * (k + 2 * R)] & 3; }
+    s.hd = init[lane]; s.hbot = init[lane + 1]; s.ebot = init[lane + 2]; s.cch = 0; s.th = init[lane + 3]; s.te = init[lane + 4];
+    s.ach = init[lane + 5] & 3; s.sh = 0; s.se = 0; s.mx = 0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) psa_step<R, false, false>(s, i, lane, 1 << 30, R, M, X, E, O);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    int acc = s.mx ^ s.hbot ^ s.ebot ^ s.sh ^ s.se;
+    for (int k = 0; k < R; ++k) acc ^= s.hl[k] ^ s.fb[k];
+    if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (acc == 0x12345678) out[0] = 0;
+}
+
+template <typename F>
+static void run(const char* name, int cells_per_step, F launch)
+{
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int ncu = prop.multiProcessorCount;
+    unsigned long long* d; hipMalloc(&d, 8 * ncu * 8 * 4);
+    unsigned* init; hipMalloc(&init, 4 * 64 * 64); hipMemset(init, 0x5a, 4 * 64 * 64);
+    const int iters = 20000;
+    printf("%-40s", name);
+    for (int w : {1, 2, 3, 4, 6, 8}) {
+        const int blocks = ncu * w;
+        launch(blocks, d, init, 100);
+        launch(blocks, d, init, iters);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks * 4);
+        hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        // SIMD throughput from the LAST wave to finish (arbitration may favour the oldest wave)
+        const double worst = (double)h.back(), med = (double)h[h.size() / 2], best = (double)h.front();
+        printf("  w=%d: %6.1f cyc/step/SIMD (%.2f/cell) [min %.0f med %.0f max %.0f]\n%-40s", w, worst / iters / w,
+               worst / iters / w / cells_per_step, best / iters, med / iters, worst / iters, "");
+    }
+    printf("\n");
+    hipFree(d); hipFree(init);
+}
+
+int main()
+{
+    const unsigned pe = 0x00020002, po = 0x00040004, pm = 0x00020002, pmx = 0x00070007;
+    run("packed R=16 full step (32 cells)", 32, [&](int b, unsigned long long* d, unsigned* in, int it) {
+        hipLaunchKernelGGL((k_pstep<16, 0>), dim3(b), dim3(256), 0, 0, d, in, it, pe, po, pm, pmx); });
+    run("packed R=16 no DPP (32 cells)", 32, [&](int b, unsigned long long* d, unsigned* in, int it) {
+        hipLaunchKernelGGL((k_pstep<16, 1>), dim3(b), dim3(256), 0, 0, d, in, it, pe, po, pm, pmx); });
+    run("packed R=8 full step (16 cells)", 16, [&](int b, unsigned long long* d, unsigned* in, int it) {
+        hipLaunchKernelGGL((k_pstep<8, 0>), dim3(b), dim3(256), 0, 0, d, in, it, pe, po, pm, pmx); });
+    run("int32 R=16 full step (16 cells)", 16, [&](int b, unsigned long long* d, unsigned* in, int it) {
+        hipLaunchKernelGGL((k_istep<16>), dim3(b), dim3(256), 0, 0, d, in, it, 2, -5, -2, -4); });
+    run("int32 R=8 full step (8 cells)", 8, [&](int b, unsigned long long* d, unsigned* in, int it) {
+        hipLaunchKernelGGL((k_istep<8>), dim3(b), dim3(256), 0, 0, d, in, it, 2, -5, -2, -4); });
+    return 0;
+}

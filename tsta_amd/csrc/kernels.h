@@ -17,10 +17,29 @@ struct PsaBatchArgs {
     unsigned int*  counter;     // ticket counter, zeroed before every launch
     int64_t        n_pairs;
     int32_t        M, X, E, O;
+    unsigned long long* clock_out;   // diagnostics only (TSTA_PSA_CLOCK=1): {memtime, memrealtime} x {begin, end} of wave 0
+    int64_t        packed_couples;  // couples (2c, 2c+1), c < packed_couples, are tried by the packed kernel first
+};
+
+// A couple of adjacent pairs goes to the packed-int16 kernel iff both pairs have the same oriented geometry
+// (columns n = longer, rows m = shorter) and are non-empty.  Evaluated identically by both kernels.
+__host__ __device__ inline bool psa_couple_is_packed(const int32_t* len1, const int32_t* len2, int64_t c)
+{
+    const int32_t a1 = len1[2 * c], a2 = len2[2 * c], b1 = len1[2 * c + 1], b2 = len2[2 * c + 1];
+    const int32_t na = a1 > a2 ? a1 : a2, ma = a1 > a2 ? a2 : a1;
+    const int32_t nb = b1 > b2 ? b1 : b2, mb = b1 > b2 ? b2 : b1;
+    return na == nb && ma == mb && ma >= 1;
+}
+
+struct PsaPackedArgs {
+    PsaBatchArgs b;                 // same batch description; b.counter -> this kernel's own ticket word
+    uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
 };
 
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream);
 int  psa_score_blocks_per_cu(int R);
 void launch_dpp_selftest(int* d_out, hipStream_t stream);
+void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream);
+int  psa_packed_blocks_per_cu(int R);
 
 }  // namespace tsta

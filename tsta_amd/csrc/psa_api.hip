@@ -1,8 +1,10 @@
 // psa_api.hip — C-ABI entry points for the PSA kernels (score-only batch).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 
 #include "../../include/tsta_engine.h"
 #include "engine.h"
@@ -26,6 +28,28 @@ static int psa_rows_per_lane(int32_t max_len)
     return max_len >= 4096 ? 16 : (max_len >= 1024 ? 8 : 4);
 }
 
+// Packed-int16 kernel eligibility (psa_score_packed.hip): returns rows per lane (16 or 8), or 0 when the scoring
+// does not fit: the kernel needs E,O <= 0 <= M, 0 <= M-X <= 255 and every value in flight within the 16-bit
+// window around the per-pair base: (64R+192)*U + |O+E| + |O| + M < 28000, U = max(M,X,0)+|O|+|E| bounding the
+// score difference of adjacent cells.
+static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples)
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char* s = getenv("TSTA_PSA_PACKED");   // tuning/debug knob: 0 = never, 8 / 16 = force rows per lane
+        mode = s ? atoi(s) : 1;
+    }
+    if (mode == 0 || couples < 1) return 0;
+    if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
+    if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
+    const int64_t U = std::max(std::max(p.M, p.X), 0) - (int64_t)p.O - (int64_t)p.E;
+    auto fits = [&](int R) { return (64LL * R + 192) * U - 2LL * p.O - p.E + p.M < 28000; };
+    if (mode == 8) return fits(8) ? 8 : 0;
+    if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
+    if (fits(16)) return 16;
+    return fits(8) ? 8 : 0;
+}
+
 }  // namespace tsta
 
 extern "C" {
@@ -43,25 +67,79 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     if (rc != TSTA_OK) return rc;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
 
+    // ---- packed-int16 kernel (K1p) for couples of equal-geometry pairs, when the scoring fits 16-bit lanes
+    const int Rp = tsta::psa_packed_rows_per_lane(*p, n_pairs / 2);
+    const int64_t couples = Rp ? n_pairs / 2 : 0;
+    int64_t pblocks = 0;
+    if (couples) {
+        pblocks = std::min<int64_t>((couples + 3) / 4, (int64_t)e->n_cu * tsta::psa_packed_blocks_per_cu(Rp));
+        if (pblocks < 1) pblocks = 1;
+    }
+    // ---- int32 kernel (K1) for everything else
     const int R = tsta::psa_rows_per_lane(max_len);
     const int per_cu = tsta::psa_score_blocks_per_cu(R);
     int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, (int64_t)e->n_cu * per_cu);
     if (blocks < 1) blocks = 1;
     const int64_t row_stride = ((int64_t)max_len + 63) / 64 * 64 + 64;
-    const size_t need = (size_t)blocks * 4 * (size_t)row_stride * sizeof(int2);
-    if ((rc = e->reserve(e->rows, need, "hipMalloc(boundary rows)")) != TSTA_OK) return rc;
+    const size_t need32 = (size_t)blocks * 4 * (size_t)row_stride * sizeof(int2);
+    const size_t need16 = (size_t)pblocks * 4 * 2 * (size_t)row_stride * sizeof(int2);
+    if ((rc = e->reserve(e->rows, need32 + need16, "hipMalloc(boundary rows)")) != TSTA_OK) return rc;
 
     tsta::PsaBatchArgs a;
     a.seqs = d_seqs; a.off1 = d_off1; a.len1 = d_len1; a.off2 = d_off2; a.len2 = d_len2; a.out = d_out;
     a.rows = reinterpret_cast<int2*>(e->rows.p); a.row_stride = row_stride;
     a.counter = reinterpret_cast<unsigned int*>(e->counter.p);
     a.n_pairs = n_pairs; a.M = p->M; a.X = p->X; a.E = p->E; a.O = p->O;
+    a.packed_couples = couples;
+    static const bool want_clock = getenv("TSTA_PSA_CLOCK") != nullptr;      // diagnostics: in-kernel shader clock
+    a.clock_out = want_clock ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->counter.p) + 64) : nullptr;
 
-    if ((rc = e->check(hipMemsetAsync(a.counter, 0, sizeof(unsigned int), s), "hipMemsetAsync")) != TSTA_OK) return rc;
+    if ((rc = e->check(hipMemsetAsync(a.counter, 0, 2 * sizeof(unsigned int), s), "hipMemsetAsync")) != TSTA_OK) return rc;
     e->timing_begin(s);
+    int launches = 0;
+    if (couples) {
+        tsta::PsaPackedArgs pa;
+        pa.b = a;
+        pa.b.rows = a.rows + need32 / sizeof(int2);
+        pa.b.counter = a.counter + 1;
+        pa.b.clock_out = nullptr;
+        if (want_clock && e->reserve(e->scratch2, (size_t)(8 + 2 * pblocks) * 8 + 64, "diag") == TSTA_OK)
+            pa.b.clock_out = reinterpret_cast<unsigned long long*>(e->scratch2.p);
+        const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
+        pa.pe = ae | (ae << 16); pa.po = ao | (ao << 16); pa.pm = am | (am << 16); pa.pmx = amx | (amx << 16);
+        tsta::launch_psa_score_packed(Rp, pa, (int)pblocks, s);
+        ++launches;
+    }
     tsta::launch_psa_score_batch(R, a, (int)blocks, s);
-    e->n_launches = 1;
+    ++launches;
+    e->n_launches = launches;
     e->timing_end(s);
+    if (want_clock) {
+        unsigned long long h[4];
+        if (hipMemcpyAsync(h, a.clock_out, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess && h[3] > h[1])
+            fprintf(stderr, "[tsta] psa_score wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks)\n",
+                    (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, R, (long long)blocks);
+        if (couples && e->scratch2.p) {
+            std::vector<unsigned long long> st(8 + 2 * pblocks);
+            if (hipMemcpy(st.data(), e->scratch2.p, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t0 = ~0ull;
+                for (int64_t b = 0; b < pblocks; ++b) t0 = std::min(t0, st[8 + b]);
+                int hist[8] = {0}; double last_end = 0;
+                for (int64_t b = 0; b < pblocks; ++b) {
+                    const double ms = (double)(st[8 + b] - t0) / 1e5;
+                    hist[std::min(7, (int)(ms / 250.0))]++;
+                    last_end = std::max(last_end, (double)(st[8 + pblocks + b] - t0) / 1e5);
+                }
+                fprintf(stderr, "[tsta] packed block start histogram (250 ms bins): %d %d %d %d %d %d %d %d; last end %.1f ms\n",
+                        hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], last_end);
+            }
+        }
+        if (couples && e->scratch2.p && hipMemcpy(h, e->scratch2.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] > h[1])
+            fprintf(stderr, "[tsta] psa_score_packed wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks, %d blocks/CU by API)\n",
+                    (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, Rp, (long long)pblocks,
+                    tsta::psa_packed_blocks_per_cu(Rp));
+    }
     return e->check(hipGetLastError(), "psa_score_batch launch");
 }
 

@@ -154,13 +154,17 @@ template <int R>
 __global__ __launch_bounds__(256) void psa_score_batch_kernel(PsaBatchArgs A)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t slot = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int2* row = A.rows + slot * A.row_stride;
+    const bool stamp = A.clock_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { A.clock_out[0] = __builtin_amdgcn_s_memtime(); A.clock_out[1] = __builtin_amdgcn_s_memrealtime(); }
     for (;;) {
         unsigned int ticket = 0;
         if (lane == 0) ticket = atomicAdd(A.counter, 1u);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if ((int64_t)ticket >= A.n_pairs) break;               // every wave reaches this exit
+        if ((int64_t)(ticket >> 1) < A.packed_couples && psa_couple_is_packed(A.len1, A.len2, ticket >> 1))
+            continue;                                           // scored by the packed-int16 kernel
         const int l1 = A.len1[ticket], l2 = A.len2[ticket];
         const uint8_t* s1 = A.seqs + A.off1[ticket];
         const uint8_t* s2 = A.seqs + A.off2[ticket];
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256) void psa_score_batch_kernel(PsaBatchArgs A)
         if (lane == 0) A.out[ticket] = max(ms, -100);           // ms = MIN (-100) floor, psa.c:110,590
         wave_mem_sync();                                        // row buffer is reused by the next pair
     }
+    if (stamp) { A.clock_out[2] = __builtin_amdgcn_s_memtime(); A.clock_out[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // DPP semantics self-test (hardware contract the DP kernels rely on).

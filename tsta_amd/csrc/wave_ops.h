@@ -26,6 +26,11 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// Opaque copy: stops the compiler from hoisting per-lane 64-bit addresses derived from `x` out of a loop and
+// keeping them live in VGPR pairs across the hot loop (they cost occupancy; recomputing them is 2-3 VALU ops
+// per 64-step block).
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }   // -> v_max3_i32
 
 // Orders this wave's own global stores before its later loads of the same bytes by OTHER lanes of the
