@@ -5,15 +5,18 @@
 // source/esource/fsource (c-t-simd.c:485-506, 530-538, 521-522/564-565) and the sinks' lastsorce (:577-578).
 // Arithmetic is the plain int32 partial-order DP the reference's saturating-int8 machinery encodes.
 //
-// v1 mapping (round 1): rows (graph nodes) are inherently ordered by the DAG, columns are not — so one
-// workgroup sweeps the nodes in topological order and spreads the COLUMNS of a node over its threads, 8
-// consecutive columns per thread:
-//   * predecessor rows H(p,.) / Eagg(p,.) are read back from HBM/L2 as two aligned 16-byte loads per array
-//     (rows are stored with a one-column shift for Eagg so both are 16-B aligned), any number of
-//     predecessors, lowest predecessor index wins ties (strict > update in ascending order);
-//   * the horizontal gap F is a max-plus prefix scan: thread-local pass, wave scan by __shfl_up, cross-wave
-//     through LDS, then a fix-up pass that also emits the three trace codes;
-//   * one __syncthreads() per row publishes the row to the later rows (same CU, write-through L1).
+// Mapping: rows (graph nodes) are ordered by the DAG, columns are not.  The (node, column) plane is cut into
+// tiles of kRB consecutive nodes (topological order) x kCW consecutive columns; ONE WAVE owns a tile and sweeps
+// its rows in order with KC columns per lane; tiles on an anti-diagonal (chunk q + row-block rb = d) are
+// independent and run as launch d (the kernel boundary is the only inter-tile synchronisation: no flags, no
+// spins, cannot deadlock).  Inside a tile:
+//   * the usual predecessor (the node just before, i.e. the POA backbone) is served from REGISTERS + one DPP
+//     lane shift; any other predecessor row H(p,.) / Eagg(p,.) is read back from HBM/L2 with aligned 16-byte
+//     loads (any number of predecessors, lowest predecessor index wins ties: strict > in ascending order);
+//   * the horizontal gap F is a max-plus prefix scan: lane-local pass, 6-step DPP wave scan (row_shr 1/2/4/8,
+//     row_bcast:15, row_bcast:31), then a fix-up pass that also emits the three trace codes;
+//   * Fbar / "open" flag / H at the tile's left edge come from the tile to the left (launch d-1), one row per
+//     lane, fetched once per tile together with the rows' DAG metadata.
 // The reference's lazy-F scalar fix-up loops (c-t-simd.c:293-329, 408-432) have no counterpart.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,196 +31,240 @@
 namespace tsta {
 
 constexpr int kNeg = -1000000000;
-constexpr int kCols = 8;                 // columns per thread per segment
+constexpr int KC = 4;                    // columns per lane
+constexpr int kCW = 64 * KC;             // columns per tile (one wave)
+constexpr int kRB = 32;                  // graph nodes (rows) per tile; <= 64 (per-row side data lives one row per lane)
 
 struct PoaArgs {
     int V, n;
     const int* pred_off; const int* pred; const uint8_t* base; const uint8_t* is_sink;
     const uint8_t* seq;                  // n bytes
-    int* Hrow;                           // [V+1][pitch]: Hrow[r][c] = H(r,c), c = 0..n      (row V = virtual init)
-    int* Erow;                           // [V+1][pitch]: Erow[r][c] = Eagg(r,c+1), c = 0..n-1
-    int64_t pitch;                       // ints per row, multiple of 8, >= n + 8
+    int* Hrow;                           // [V+1][pitch]: Hrow[r][c+3] = H(r,c), c = 0..n   (row V = virtual init)
+    int* Erow;                           // [V+1][pitch]: Erow[r][c]   = Eagg(r,c+1), c = 0..n-1
+    int64_t pitch;                       // ints per row, multiple of 4
+    int* carry;                          // [V][nchunks+1]: Fbar entering chunk q of row r
+    uint8_t* cflag;                      // [V][nchunks+1]: "F at the first column of chunk q is an open"
+    int nchunks, nrb, d, q_lo;           // launch d runs the tiles (q, rb = d - q)
     int8_t* source; int8_t* esource; int8_t* fsource; int64_t tpitch;   // [V][tpitch] device layout (tpitch mult. of 8)
     int* lastscore;                      // [V]
     int* best;                           // [0] = best sink
     int M, X, E, O;
 };
 
-__global__ __launch_bounds__(1024) void poa_fill_kernel(PoaArgs A)
+__device__ __forceinline__ int dpp_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
+
+__global__ void poa_init_kernel(PoaArgs A)
 {
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
-    const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
-    const int a8 = kCols * E;
-    __shared__ int wtot[16];
-    __shared__ int segcarry;             // Fbar entering the current segment
-    __shared__ int openflag[1025];       // "F at next column is an open" of each thread's last column; [0] = segment-in
-
     // virtual init row (c-t-simd.c:82-94,174-188): H = 0, O+c*E ; no vertical gap state
-    {
-        int* Hi = A.Hrow + (size_t)A.V * A.pitch; int* Ei = A.Erow + (size_t)A.V * A.pitch;
-        for (int c = tid; c <= n; c += T) { Hi[c] = c == 0 ? 0 : O + c * E; Ei[c] = kNeg; }
+    int* Hi = A.Hrow + (size_t)A.V * A.pitch; int* Ei = A.Erow + (size_t)A.V * A.pitch;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= A.n; c += gridDim.x * blockDim.x) {
+        Hi[c + 3] = c == 0 ? 0 : A.O + c * A.E;
+        Ei[c] = kNeg;
     }
-    __syncthreads();
+}
 
-    const int seg_cols = T * kCols;
-    for (int r = 0; r < A.V; ++r) {
-        int p0 = A.pred_off[r], np = A.pred_off[r + 1] - p0;
+// One wave = one tile: kRB consecutive nodes (topological order) x kCW consecutive columns, rows in order,
+// KC columns per lane.  Tiles on the anti-diagonal q + rb = d are independent (launch d).
+__global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
+{
+    const int lane = threadIdx.x;
+    const int q = A.q_lo + blockIdx.x, rb = A.d - q;
+    const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
+    const int aK = KC * E;
+    const int r0 = rb * kRB, r1 = min(A.V, r0 + kRB);
+    const int cbase = q * kCW, c0 = cbase + lane * KC;     // this lane owns 1-based columns c0+1 .. c0+KC
+    const int ncar = A.nchunks + 1;
+
+    int sch[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) sch[k] = (c0 + k < n) ? (int)A.seq[c0 + k] : -1;
+
+    // per-row side data of this tile, row r0+i in lane i
+    int xin_l = 0, flag_l = 1, edge_l = 0;
+    if (q > 0 && r0 + lane < r1) {
+        xin_l = A.carry[(size_t)(r0 + lane) * ncar + q];
+        flag_l = A.cflag[(size_t)(r0 + lane) * ncar + q];
+        edge_l = A.Hrow[(size_t)(r0 + lane) * A.pitch + cbase + 3];       // H(row, column cbase) from tile q-1
+    }
+    // DAG metadata of the tile's rows, one row per lane (avoids dependent scalar loads on the per-row critical path)
+    int poff_l = 0, np_l = 0, base_l = 0, pfirst_l = -1;
+    if (r0 + lane < r1) {
+        poff_l = A.pred_off[r0 + lane];
+        np_l = A.pred_off[r0 + lane + 1] - poff_l;
+        base_l = A.base[r0 + lane];
+        if (np_l > 0) pfirst_l = A.pred[poff_l];
+    }
+    // scan weights: distance (in lanes) to the source lane of the two cross-row DPP broadcasts
+    const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
+    int cout_l = 0, fout_l = 0;
+
+    int hs_prev[KC], es_prev[KC], prev_r = -2, h0_prev = 0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { hs_prev[k] = 0; es_prev[k] = 0; }
+
+    for (int r = r0; r < r1; ++r) {
+        const int i = r - r0;
+        const int p0 = __builtin_amdgcn_readlane(poff_l, i), np = __builtin_amdgcn_readlane(np_l, i);
+        const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i);
         const bool is_src = (np == 0);                       // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
         int* Hr = A.Hrow + (size_t)r * A.pitch;
         int* Er = A.Erow + (size_t)r * A.pitch;
-        const int bs = A.base[r];
-        // first column (c-t-simd.c:187,194-200)
-        int h0;
-        if (is_src) h0 = OE;
-        else {
-            h0 = kNeg;
-            for (int j = 0; j < np; ++j) h0 = max(h0, A.Hrow[(size_t)A.pred[p0 + j] * A.pitch]);
-            h0 += E;
+        const int bs = __builtin_amdgcn_readlane(base_l, i);
+        // first column (c-t-simd.c:187,194-200) - chunk 0 only
+        int h0 = 0, xin_row, flag_row;
+        if (q == 0) {
+            if (is_src) h0 = OE;
+            else {
+                h0 = kNeg;
+                for (int j = 0; j < np; ++j) {
+                    const int p = (j == 0) ? pfirst : A.pred[p0 + j];
+                    h0 = max(h0, (p == prev_r) ? h0_prev : A.Hrow[(size_t)p * A.pitch + 3]);
+                }
+                h0 += E;
+            }
+            xin_row = h0 + O; flag_row = 1;                  // F(r,0) = -inf: the first F is an open
+        } else {
+            xin_row = __builtin_amdgcn_readlane(xin_l, i);
+            flag_row = __builtin_amdgcn_readlane(flag_l, i);
         }
-        if (tid == 0) { Hr[0] = h0; segcarry = h0 + O; openflag[0] = 1; }   // F(r,0) = -inf: first F is an open
-        __syncthreads();
 
-        for (int sb = 0; sb < n; sb += seg_cols) {
-            const int c0 = sb + tid * kCols;                 // this thread owns columns c0+1 .. c0+8 (1-based)
-            int bq[kCols], jq[kCols], be[kCols], je[kCols], sc[kCols];
-            bool mt[kCols];
+        int bq[KC], jq[KC], be[KC], je[KC], sc[KC];
+        bool mt[KC];
 #pragma unroll
-            for (int k = 0; k < kCols; ++k) {
-                const int c = c0 + k;                        // 0-based column index of seq
-                const int ch = (c < n) ? (int)A.seq[c] : -1;
-                mt[k] = (ch == bs);
-                sc[k] = mt[k] ? M : X;
-                bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0;
-            }
-            if (c0 < n) {
-                const int npp = is_src ? 1 : np;
-                for (int j = 0; j < npp; ++j) {
-                    const int p = is_src ? A.V : A.pred[p0 + j];
-                    const int* Hp = A.Hrow + (size_t)p * A.pitch + c0;     // H(p, c0 .. c0+8)
-                    const int* Ep = A.Erow + (size_t)p * A.pitch + c0;     // Eagg(p, c0+1 .. c0+8)
-                    const int4 ha = *reinterpret_cast<const int4*>(Hp);
-                    const int4 hb = *reinterpret_cast<const int4*>(Hp + 4);
-                    const int h8 = Hp[8];
-                    const int4 ea = *reinterpret_cast<const int4*>(Ep);
-                    const int4 eb = *reinterpret_cast<const int4*>(Ep + 4);
-                    const int hv[9] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w, h8};
-                    const int ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-#pragma unroll
-                    for (int k = 0; k < kCols; ++k) {
-                        const int q = hv[k] + sc[k];                       // diagonal from H(p, c-1)
-                        if (q > bq[k]) { bq[k] = q; jq[k] = j; }
-                        const int eo = hv[k + 1] + OE, ex = ev[k] + E;     // c-t-simd.c:524-528
-                        const int ein = max(ex, eo);
-                        if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
-                    }
-                }
-            }
-            // ---- F: local pass with no carry-in
-            int fbar = kNeg;
-#pragma unroll
-            for (int k = 0; k < kCols; ++k) {
-                const int f = fbar + E;
-                const int h = max(max(bq[k], be[k]), f);
-                fbar = max(f, h + O);
-            }
-            // ---- max-plus inclusive scan of (b, shift a8 per thread)
-            int v = fbar;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int u = __shfl_up(v, off, 64);
-                if (lane >= off) v = max(v, u + off * a8);
-            }
-            if (lane == 63) wtot[wv] = v;
-            __syncthreads();
-            int pw = kNeg;                                   // prefix of the previous waves, aligned to lane -1
-            for (int w2 = 0; w2 < wv; ++w2) pw = max(pw, wtot[w2] + (wv - 1 - w2) * 64 * a8);
-            const int incl = max(v, pw + (lane + 1) * a8);   // I_g
-            int prev = __shfl_up(incl, 1, 64);               // I_{g-1}
-            if (lane == 0) prev = pw;                        // previous wave's inclusive value at its lane 63
-            const int sc_in = segcarry;
-            int xin = max(prev, sc_in + tid * a8);           // Fbar entering this thread's first column
-            if (tid == 0) xin = sc_in;
-            __syncthreads();                                 // everyone has read segcarry / wtot
-            if (tid == T - 1) segcarry = max(incl, sc_in + T * a8);
-            // ---- fix-up pass with the true carry: final H, Eagg, trace codes
-            fbar = xin;
-            int hl[kCols], fl[kCols];
-            bool opn[kCols + 1];                             // opn[k]: F at column k is an open (from column k-1)
-            opn[0] = false;
-#pragma unroll
-            for (int k = 0; k < kCols; ++k) {
-                const int f = fbar + E;
-                const int h = max(max(bq[k], be[k]), f);
-                hl[k] = h; fl[k] = f;
-                const int g = h + O;
-                opn[k + 1] = (g >= f);                       // F(c+1) == H(c)+O+E  <=>  H(c)+O >= F(c)
-                fbar = max(f, g);
-            }
-            openflag[tid + 1] = opn[kCols] ? 1 : 0;
-            bool f0neg = false;                              // sign of fsource at the thread's first column
-            if (c0 < n) {
-                int hs[kCols], es[kCols];
-                int8_t s1[kCols], s2[kCols], s3[kCols];
-#pragma unroll
-                for (int k = 0; k < kCols; ++k) {
-                    const int h = hl[k], f = fl[k];
-                    hs[k] = h; es[k] = be[k];
-                    // source: match > mismatch > E > F, lowest predecessor index (c-t-simd.c:485-506)
-                    int code;
-                    if (bq[k] == h) code = (mt[k] ? 42 : 84) + jq[k];
-                    else if (be[k] == h) code = je[k] & 63;
-                    else code = 126;
-                    s1[k] = (int8_t)code;
-                    int ecode = ((je[k] & 64) ? 43 : 1) + (je[k] & 63);            // c-t-simd.c:530-538
-                    if (be[k] + E == h + OE) ecode = -ecode;
-                    s2[k] = (int8_t)ecode;
-                    int fcode = (k > 0 && opn[k]) ? 2 : 1;                          // k==0 patched after the barrier
-                    if (f + E == h + OE) fcode = -fcode;
-                    if (k == 0) f0neg = (fcode < 0);
-                    s3[k] = (int8_t)fcode;
-                }
-                // rows for the later nodes (H at c0+1..c0+8 -> index c0+1.., Eagg at c0+1.. -> index c0..)
-#pragma unroll
-                for (int k = 0; k < kCols; ++k) if (c0 + k < n) { Hr[c0 + 1 + k] = hs[k]; Er[c0 + k] = es[k]; }
-                if (A.source) {
-                    int8_t* d1 = A.source + (size_t)r * A.tpitch + c0;
-                    int8_t* d2 = A.esource + (size_t)r * A.tpitch + c0;
-                    int8_t* d3 = A.fsource + (size_t)r * A.tpitch + c0;
-                    uint2 w1, w2, w3;
-                    w1.x = (uint8_t)s1[0] | ((uint8_t)s1[1] << 8) | ((uint8_t)s1[2] << 16) | ((unsigned)(uint8_t)s1[3] << 24);
-                    w1.y = (uint8_t)s1[4] | ((uint8_t)s1[5] << 8) | ((uint8_t)s1[6] << 16) | ((unsigned)(uint8_t)s1[7] << 24);
-                    w2.x = (uint8_t)s2[0] | ((uint8_t)s2[1] << 8) | ((uint8_t)s2[2] << 16) | ((unsigned)(uint8_t)s2[3] << 24);
-                    w2.y = (uint8_t)s2[4] | ((uint8_t)s2[5] << 8) | ((uint8_t)s2[6] << 16) | ((unsigned)(uint8_t)s2[7] << 24);
-                    w3.x = (uint8_t)s3[0] | ((uint8_t)s3[1] << 8) | ((uint8_t)s3[2] << 16) | ((unsigned)(uint8_t)s3[3] << 24);
-                    w3.y = (uint8_t)s3[4] | ((uint8_t)s3[5] << 8) | ((uint8_t)s3[6] << 16) | ((unsigned)(uint8_t)s3[7] << 24);
-                    *reinterpret_cast<uint2*>(d1) = w1;
-                    *reinterpret_cast<uint2*>(d2) = w2;
-                    *reinterpret_cast<uint2*>(d3) = w3;
-                }
-                if (c0 + kCols >= n && c0 < n) {             // owner of the last column
-                    const int kl = n - 1 - c0;
-                    int hlast = hs[0];
-#pragma unroll
-                    for (int k = 1; k < kCols; ++k) if (k == kl) hlast = hs[k];
-                    A.lastscore[r] = hlast;
-                }
-            }
-            __syncthreads();                                 // row (segment) + open flags published
-            if (c0 < n && A.fsource) {
-                // first column of the thread: the open flag comes from the thread on the left
-                if (openflag[tid]) A.fsource[(size_t)r * A.tpitch + c0] = (int8_t)(f0neg ? -2 : 2);   // +-1 -> +-2
-            }
-            __syncthreads();
-            if (tid == 0) openflag[0] = openflag[T];         // carry the flag into the next segment
-            __syncthreads();
+        for (int k = 0; k < KC; ++k) {
+            mt[k] = (sch[k] == bs);
+            sc[k] = mt[k] ? M : X;
+            bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0;
         }
+        const int npp = is_src ? 1 : np;
+        bool synced = false;
+        for (int j = 0; j < npp; ++j) {
+            const int p = is_src ? A.V : ((j == 0) ? pfirst : A.pred[p0 + j]);
+            int hv[KC + 1], ev[KC];
+            if (p == prev_r) {
+                // predecessor = the row this wave has just finished: registers + one lane shift, no memory
+                const int edge = (q == 0) ? h0_prev : __builtin_amdgcn_readlane(edge_l, i - 1);
+                hv[0] = dpp_shr1(edge, hs_prev[KC - 1]);
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { hv[k + 1] = hs_prev[k]; ev[k] = es_prev[k]; }
+            } else {
+                if (p >= r0 && p < r1 && !synced) {          // written by this wave earlier in this tile
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    synced = true;
+                }
+                const int* Hp = A.Hrow + (size_t)p * A.pitch + c0 + 3;     // H(p, c0 .. c0+KC)
+                const int* Ep = A.Erow + (size_t)p * A.pitch + c0;         // Eagg(p, c0+1 .. c0+KC)
+                hv[0] = Hp[0];
+                const int4 ha = *reinterpret_cast<const int4*>(Hp + 1);
+                const int4 ea = *reinterpret_cast<const int4*>(Ep);
+                hv[1] = ha.x; hv[2] = ha.y; hv[3] = ha.z; hv[4] = ha.w;
+                ev[0] = ea.x; ev[1] = ea.y; ev[2] = ea.z; ev[3] = ea.w;
+            }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int qv = hv[k] + sc[k];                              // diagonal from H(p, c-1)
+                if (qv > bq[k]) { bq[k] = qv; jq[k] = j; }                 // lowest predecessor index on ties
+                const int eo = hv[k + 1] + OE, ex = ev[k] + E;             // c-t-simd.c:524-528
+                const int ein = max(ex, eo);
+                if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
+            }
+        }
+        // ---- F: local pass with no carry-in, then a max-plus inclusive scan over the 64 lanes
+        int fbar = kNeg;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int f = fbar + E;
+            const int h = max(max(bq[k], be[k]), f);
+            fbar = max(f, h + O);
+        }
+        // DPP wave scan (VALU only): row_shr 1,2,4,8 inside each 16-lane row, then row_bcast:15 / row_bcast:31
+        int v = fbar;
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false) + aK);
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false) + 2 * aK);
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false) + 4 * aK);
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false) + 8 * aK);
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false) + w15);
+        v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
+        const int prev = dpp_shr1(kNeg, v);
+        const int xin = max(prev, xin_row + lane * aK);      // Fbar entering this lane's first column
+        const int xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);   // ... entering the next chunk
+        // ---- fix-up pass with the true carry: final H, Eagg, trace codes
+        fbar = xin;
+        int hs[KC], es[KC], fl[KC];
+        bool opn[KC + 1];
+        opn[0] = false;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int f = fbar + E;
+            const int h = max(max(bq[k], be[k]), f);
+            hs[k] = h; fl[k] = f; es[k] = be[k];
+            const int g = h + O;
+            opn[k + 1] = (g >= f);                           // F(c+1) == H(c)+O+E  <=>  H(c)+O >= F(c)
+            fbar = max(f, g);
+        }
+        // open flag of the lane's first column comes from the lane on the left (or the chunk/row boundary)
+        const int opn_last = opn[KC] ? 1 : 0;
+        opn[0] = dpp_shr1(flag_row, opn_last) != 0;
+        const int flag_out = __builtin_amdgcn_readlane(opn_last, 63);
+        if (lane == i) { cout_l = xout; fout_l = flag_out; }
+
+        if (c0 < n) {
+            unsigned w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int h = hs[k], f = fl[k];
+                int code;                                    // match > mismatch > E > F (c-t-simd.c:485-506)
+                if (bq[k] == h) code = (mt[k] ? 42 : 84) + jq[k];
+                else if (be[k] == h) code = je[k] & 63;
+                else code = 126;
+                int ecode = ((je[k] & 64) ? 43 : 1) + (je[k] & 63);        // c-t-simd.c:530-538
+                if (be[k] + E == h + OE) ecode = -ecode;
+                int fcode = opn[k] ? 2 : 1;                                // c-t-simd.c:521-522,564-565
+                if (f + E == h + OE) fcode = -fcode;
+                w1 |= (unsigned)(uint8_t)code << (8 * k);
+                w2 |= (unsigned)(uint8_t)ecode << (8 * k);
+                w3 |= (unsigned)(uint8_t)fcode << (8 * k);
+            }
+            *reinterpret_cast<int4*>(Hr + c0 + 4) = make_int4(hs[0], hs[1], hs[2], hs[3]);     // H(r, c0+1..c0+4)
+            *reinterpret_cast<int4*>(Er + c0) = make_int4(es[0], es[1], es[2], es[3]);
+            if (A.source) {
+                *reinterpret_cast<unsigned*>(A.source + (size_t)r * A.tpitch + c0) = w1;
+                *reinterpret_cast<unsigned*>(A.esource + (size_t)r * A.tpitch + c0) = w2;
+                *reinterpret_cast<unsigned*>(A.fsource + (size_t)r * A.tpitch + c0) = w3;
+            }
+            if (c0 + KC >= n) {                              // owner of the last column
+                const int kl = n - 1 - c0;
+                int hlast = hs[0];
+#pragma unroll
+                for (int k = 1; k < KC; ++k) if (k == kl) hlast = hs[k];
+                A.lastscore[r] = hlast;
+            }
+        }
+        if (q == 0 && lane == 0) Hr[3] = h0;                 // H(r, 0)
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { hs_prev[k] = hs[k]; es_prev[k] = es[k]; }
+        prev_r = r; h0_prev = h0;
     }
-    // best sink: max lastscore, ties -> lowest index (c-t-simd.c:737-750)
+    if (r0 + lane < r1) {
+        A.carry[(size_t)(r0 + lane) * ncar + q + 1] = cout_l;
+        A.cflag[(size_t)(r0 + lane) * ncar + q + 1] = (uint8_t)fout_l;
+    }
+}
+
+// best sink: max lastscore, ties -> lowest index (c-t-simd.c:737-750)
+__global__ void poa_best_kernel(PoaArgs A)
+{
+    __shared__ int bv[256], bi[256];
+    int best = -1, val = 0;
+    for (int r = threadIdx.x; r < A.V; r += blockDim.x)
+        if (A.is_sink[r] && (best < 0 || A.lastscore[r] > val)) { best = r; val = A.lastscore[r]; }
+    bv[threadIdx.x] = val; bi[threadIdx.x] = best;
     __syncthreads();
-    if (tid == 0) {
-        int best = -1, bv = 0;
-        for (int r = 0; r < A.V; ++r)
-            if (A.is_sink[r] && (best < 0 || A.lastscore[r] > bv)) { best = r; bv = A.lastscore[r]; }
+    if (threadIdx.x == 0) {
+        for (int t = 1; t < (int)blockDim.x; ++t)
+            if (bi[t] >= 0 && (best < 0 || bv[t] > val || (bv[t] == val && bi[t] < best))) { best = bi[t]; val = bv[t]; }
         A.best[0] = best;
     }
 }
@@ -248,13 +295,16 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
 
-    const int64_t pitch = ((int64_t)n + 8 + 7) / 8 * 8 + 8;
-    const int64_t tpitch = ((int64_t)n + 7) / 8 * 8;
+    const int nchunks = (n + tsta::kCW - 1) / tsta::kCW, nrb = (V + tsta::kRB - 1) / tsta::kRB;
+    const int64_t pitch = ((int64_t)nchunks * tsta::kCW + 8 + 3) / 4 * 4 + 8;
+    const int64_t tpitch = (int64_t)nchunks * tsta::kCW;
     const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 4 + (size_t)V * 2 + (size_t)n + 64;
     const size_t rows_bytes = (size_t)(V + 1) * pitch * sizeof(int);
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)")) ||
         (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)")) ||
-        (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)")))
+        (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)")) ||
+        (rc = e->reserve(e->scratch, (size_t)V * (nchunks + 1) * 4 + 64, "hipMalloc(poa carry)")) ||
+        (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)")))
         return rc;
     if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch, "hipMalloc(poa trace)"))) return rc;
 
@@ -277,6 +327,9 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     A.Erow = A.Hrow + (size_t)(V + 1) * pitch;
     A.pitch = pitch;
     A.tpitch = tpitch;
+    A.carry = reinterpret_cast<int*>(e->scratch.p);
+    A.cflag = reinterpret_cast<uint8_t*>(e->scratch2.p);
+    A.nchunks = nchunks; A.nrb = nrb;
     A.source = want_trace ? reinterpret_cast<int8_t*>(e->trace.p) : nullptr;
     A.esource = want_trace ? A.source + (size_t)V * tpitch : nullptr;
     A.fsource = want_trace ? A.esource + (size_t)V * tpitch : nullptr;
@@ -284,11 +337,17 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     A.best = reinterpret_cast<int*>(e->counter.p);
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
 
-    int threads = ((n + kCols - 1) / kCols + 63) / 64 * 64;
-    threads = std::max(64, std::min(1024, threads));
     e->timing_begin(s);
-    hipLaunchKernelGGL(poa_fill_kernel, dim3(1), dim3(threads), 0, s, A);
-    e->n_launches = 1;
+    hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
+    int launches = 1;
+    for (int d = 0; d < nchunks + nrb - 1; ++d) {            // tile anti-diagonals: q + rb = d
+        const int q_lo = std::max(0, d - nrb + 1), q_hi = std::min(nchunks - 1, d);
+        A.d = d; A.q_lo = q_lo;
+        hipLaunchKernelGGL(poa_tile_kernel, dim3(q_hi - q_lo + 1), dim3(64), 0, s, A);
+        ++launches;
+    }
+    hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
+    e->n_launches = launches + 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_fill launch"))) return rc;
 
