@@ -18,9 +18,10 @@
 // The reference's fback(i,j) in {1,2,-2} is (Fopen(i,j), Ftie(i,j)); Fopen(i,j) is stored one cell to the
 // left (it is known when F(i,j-1) is formed), the walker looks there.  Same for eback one cell up.
 //
-// K3.  One wave walks the path: the wave stages a window of the trace (one band, NQ 1-KiB step groups) in LDS,
-// lane 0 walks inside it (psa.c:441-463 incl. the forced-continuation overwrite), emitting one op per
-// alignment column; cells outside the window (band crossings) are read straight from HBM.
+// K3.  One wave walks the path: it stages a window of the trace (one band, NQ 1-KiB step groups) in LDS; runs of
+// diagonal moves are taken 64 cells at a time (lane l probes cell (i-l, j-l), ballot + count-trailing-zeros);
+// gap moves follow psa.c:441-463 incl. the forced-continuation overwrite; one op per alignment column is
+// emitted; cells outside the window (band crossings) are read straight from HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -241,66 +242,94 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(WalkArgs A)
     constexpr int BAND = 64 * R;
     __shared__ uint4 win[NQ * 64];
     const int lane = threadIdx.x;
-    int i = A.m, j = A.n;            // 1-based current cell
+    int i = A.m, j = A.n;            // 1-based current cell (wave-uniform)
     int forced = -1;
     int cnt = 0;
     while (i >= 1 && j >= 1) {
-        // stage the window that ends at the current cell's step group
+        // stage the window that ends at the current cell's step group (one band, NQ step groups of 1 KiB)
         const int w = (i - 1) / BAND;
         const int ln = ((i - 1) % BAND) / R;
         const int qhi = (j - 1 + ln) / SPB;
         const int qlo = max(0, qhi - (NQ - 1));
         const uint4* src = reinterpret_cast<const uint4*>(A.trace + (size_t)w * A.band_bytes) + (size_t)qlo * 64;
         const int nq = qhi - qlo + 1;
-        for (int x = lane; x < nq * 64; x += 64) win[x] = src[x];
+        {
+            // all loads of the window in flight at once (the trace is cold in HBM: ~2 us per dependent round trip)
+            uint4 tmp[NQ];
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) tmp[x] = (x < nq) ? src[x * 64 + lane] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) win[x * 64 + lane] = tmp[x];
+        }
         __syncthreads();
-        if (lane == 0) {
-            const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
-            auto code = [&](int ci, int cj) -> unsigned {       // trace byte of cell (ci,cj), 1-based, ci,cj >= 1
-                const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
-                const int ct = cj - 1 + cl, cq = ct / SPB;
-                const size_t off = ((size_t)cq * 64 + cl) * 16 + (ct % SPB) * R + ck;
-                if (cw == w && cq >= qlo && cq <= qhi) return wb[off - (size_t)qlo * 64 * 16];
-                return A.trace[(size_t)cw * A.band_bytes + off];
-            };
-            for (;;) {
-                if (i < 1 || j < 1) break;
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+        // trace byte of cell (ci,cj), 1-based; *inwin tells whether it came from the staged window
+        auto code = [&](int ci, int cj) -> unsigned {
+            const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
+            const int ct = cj - 1 + cl, cq = ct / SPB;
+            const size_t off = ((size_t)cq * 64 + cl) * 16 + (ct % SPB) * R + ck;
+            if (cw == w && cq >= qlo && cq <= qhi) return wb[off - (size_t)qlo * 64 * 16];
+            return A.trace[(size_t)cw * A.band_bytes + off];
+        };
+        for (;;) {
+            if (i < 1 || j < 1) break;
+            {
                 const int cw = (i - 1) / BAND, cl = ((i - 1) % BAND) / R;
                 const int cq = (j - 1 + cl) / SPB;
                 if (cw != w || cq < qlo) break;                  // left the window: restage
-                const unsigned c = code(i, j);
-                int k;
-                if (forced >= 0) { k = forced; forced = -1; }
-                else k = !(c & 1u) ? 1 : (!(c & 2u) ? 0 : 2);     // psa.c:443-455: diag > left > up
-                A.ops[cnt++] = (uint8_t)k;
-                if (k == 1) { --i; --j; }
-                else if (k == 0) {
-                    // psa.c:450-452: continue left if F(i,j) was an extension, or it was opened and the cell to the
-                    // left is "opened & tied"
-                    if (j - 1 >= 1) {
-                        const unsigned cl1 = code(i, j - 1);
-                        const bool fopen_ij = ((cl1 >> 2) & 3u) >= 1u;                       // Fopen(i,j) stored at (i,j-1)
-                        const bool ftie_l = ((cl1 >> 2) & 3u) == 1u;                         // Ftie(i,j-1)
-                        const bool fopen_l = (j - 1 == 1) ? true : (((code(i, j - 2) >> 2) & 3u) >= 1u);   // Fopen(i,j-1)
-                        if (!fopen_ij || (fopen_l && ftie_l)) forced = 0;
+            }
+            if (forced < 0) {
+                // ---- diagonal run: lane l probes cell (i-l, j-l); the run of leading "diag" cells is taken at once
+                const int ci = i - lane, cj = j - lane;
+                bool isdiag = false;
+                if (ci >= 1 && cj >= 1) {
+                    const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
+                    const int ct = cj - 1 + cl, cq = ct / SPB;
+                    if (cw == w && cq >= qlo) {
+                        const size_t off = ((size_t)(cq - qlo) * 64 + cl) * 16 + (ct % SPB) * R + ck;
+                        isdiag = !(wb[off] & 1u);                 // psa.c:443: back == 1
                     }
-                    --j;
-                } else {
-                    if (i - 1 >= 1) {                                                       // psa.c:457-459
-                        const unsigned cu1 = code(i - 1, j);
-                        const bool eopen_ij = ((cu1 >> 4) & 3u) >= 1u;                       // Eopen(i,j) stored at (i-1,j)
-                        const bool etie_u = ((cu1 >> 4) & 3u) == 1u;                         // Etie(i-1,j)
-                        const bool eopen_u = (i - 1 == 1) ? true : (((code(i - 2, j) >> 4) & 3u) >= 1u);   // Eopen(i-1,j)
-                        if (!eopen_ij || (eopen_u && etie_u)) forced = 2;
-                    }
-                    --i;
+                }
+                const unsigned long long mask = __ballot(isdiag);
+                const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
+                if (run > 0) {
+                    if (lane < run) A.ops[cnt + lane] = 1;
+                    i -= run; j -= run; cnt += run;
+                    continue;
                 }
             }
+            // ---- one non-diagonal (or forced) step, computed identically by every lane
+            const unsigned c = __builtin_amdgcn_readfirstlane(code(i, j));
+            int k;
+            if (forced >= 0) { k = forced; forced = -1; }
+            else k = !(c & 1u) ? 1 : (!(c & 2u) ? 0 : 2);         // psa.c:443-455: diag > left > up
+            if (lane == 0) A.ops[cnt] = (uint8_t)k;
+            ++cnt;
+            if (k == 1) { --i; --j; }
+            else if (k == 0) {
+                // psa.c:450-452: continue left if F(i,j) was an extension, or it was opened and the cell to the
+                // left is "opened & tied"
+                if (j - 1 >= 1) {
+                    const unsigned cl1 = __builtin_amdgcn_readfirstlane(code(i, j - 1));
+                    const bool fopen_ij = ((cl1 >> 2) & 3u) >= 1u;                       // Fopen(i,j) stored at (i,j-1)
+                    const bool ftie_l = ((cl1 >> 2) & 3u) == 1u;                         // Ftie(i,j-1)
+                    bool fopen_l = true;                                                 // Fopen(i,j-1)
+                    if (j - 1 != 1) fopen_l = ((__builtin_amdgcn_readfirstlane(code(i, j - 2)) >> 2) & 3u) >= 1u;
+                    if (!fopen_ij || (fopen_l && ftie_l)) forced = 0;
+                }
+                --j;
+            } else {
+                if (i - 1 >= 1) {                                                       // psa.c:457-459
+                    const unsigned cu1 = __builtin_amdgcn_readfirstlane(code(i - 1, j));
+                    const bool eopen_ij = ((cu1 >> 4) & 3u) >= 1u;                       // Eopen(i,j) stored at (i-1,j)
+                    const bool etie_u = ((cu1 >> 4) & 3u) == 1u;                         // Etie(i-1,j)
+                    bool eopen_u = true;                                                 // Eopen(i-1,j)
+                    if (i - 1 != 1) eopen_u = ((__builtin_amdgcn_readfirstlane(code(i - 2, j)) >> 4) & 3u) >= 1u;
+                    if (!eopen_ij || (eopen_u && etie_u)) forced = 2;
+                }
+                --i;
+            }
         }
-        i = __builtin_amdgcn_readfirstlane(i);
-        j = __builtin_amdgcn_readfirstlane(j);
-        forced = __builtin_amdgcn_readfirstlane(forced);
-        cnt = __builtin_amdgcn_readfirstlane(cnt);
         __syncthreads();
     }
     if (lane == 0) { A.out[2] = cnt; A.out[3] = i; A.out[4] = j; }
@@ -311,7 +340,8 @@ static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, c
                      int32_t* maxscore, int32_t* end_score, std::vector<uint8_t>& ops, int& fi, int& fj)
 {
     constexpr int NS = TraceCfg<R>::NS;
-    const int T = 128;
+    static const int T_env = getenv("TSTA_TRACE_T") ? atoi(getenv("TSTA_TRACE_T")) : 0;    // tuning knob (multiple of 64)
+    const int T = (T_env >= 64 && T_env % 64 == 0) ? T_env : 64;
     const int W = (m + 64 * R - 1) / (64 * R);
     const int S_total = (n + 64 + 63) / 64 * 64;
     const int64_t row_stride = S_total + 64;
@@ -399,8 +429,10 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
     int32_t ms = -100, es = 0;
     if (m > 0 && n > 0) {
         // rows per lane: small bands expose more concurrent bands of the single pair
-        if (m >= 16384) rc = run_align<4>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
-        else            rc = run_align<2>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
+        static const int R_env = getenv("TSTA_TRACE_R") ? atoi(getenv("TSTA_TRACE_R")) : 0;   // tuning knob: 2 or 4
+        const int Rsel = (R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
+        if (Rsel == 4) rc = run_align<4>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
+        else           rc = run_align<2>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
         if (rc != TSTA_OK) return rc;
     }
     // psa.c:464-516: leftover prefix of a against gaps, leftover prefix of b against gaps, then reverse
