@@ -1,0 +1,80 @@
+"""TSTA_msa drop-in: host graph code (tsta_amd/host/poa_graph.c: node_fuse, t_sort, printf_result restatement).
+CPU: driven by the oracle's fill through tests/host/msa_oracle_main.c, compared with the reference's output-file
+md5, stdout and stderr (tests/golden/msa_golden.json, made by tests/golden/make_msa_golden.py from the compiled
+reference).  GPU: the real TSTA_msa CLI (fill on the MI355X) against the same golden data."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from tests import util
+from tests.golden.make_msa_golden import case_seqs
+from tests.golden.make_poa_golden import write_multi_fasta
+
+with open(os.path.join(util.GOLDEN_DIR, "msa_golden.json")) as f:
+    GOLDEN = json.load(f)
+HOST = os.path.join(util.ROOT, "tsta_amd", "host")
+BIN = os.path.join(util.ROOT, "tsta_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def oracle_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("msa") / "msa_oracle_main")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-o", exe, os.path.join(util.ROOT, "tests", "host", "msa_oracle_main.c"),
+                           os.path.join(HOST, "msa_driver.c"), os.path.join(HOST, "poa_graph.c"), os.path.join(HOST, "fasta.c"),
+                           os.path.join(util.ORACLE_DIR, "poa_oracle.c"), "-lz", "-lpthread"])
+    return exe
+
+
+def input_path(c, tmp_path):
+    if c["kind"] == "example":
+        return os.path.join(util.GOLDEN_DIR, "msa_seq1.fa")
+    fa = str(tmp_path / "in.fa")
+    write_multi_fasta(fa, case_seqs(c))
+    return fa
+
+
+def check(c, r, out):
+    assert r.returncode == 0, r.stderr[-500:]
+    data = open(out, "rb").read()
+    assert len(data) == c["size"] and hashlib.md5(data).hexdigest() == c["md5"]
+    assert r.stdout.decode() == c["stdout"] and r.stderr.decode().endswith(c["stderr"])      # "[N/N]" / "seq_num: N"
+
+
+@pytest.mark.parametrize("idx", range(len(GOLDEN)))
+def test_host_graph_code_with_oracle_fill(oracle_driver, tmp_path, idx):
+    c = GOLDEN[idx]
+    sc = c["scoring"]
+    out = str(tmp_path / "out.txt")
+    r = subprocess.run([oracle_driver, str(sc["M"]), str(sc["X"]), str(sc["E"]), str(sc["O"]), input_path(c, tmp_path), out],
+                       capture_output=True, timeout=600)
+    check(c, r, out)
+
+
+def test_readme_example_md5():
+    ex = [g for g in GOLDEN if g["kind"] == "example"]
+    assert ex[0]["md5"] == "e7b253a265351c1e4f97dd3b663da7ee" and ex[1]["md5"] == "6565a80a6e6aa652b2553ef87c671d06"
+
+
+def test_msa_usage_matches_reference():
+    import tsta_amd
+    tsta_amd.build()
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    ours = subprocess.run([os.path.join(BIN, "TSTA_msa")], capture_output=True, timeout=60)
+    assert ours.returncode == 0 and ours.stdout.startswith(b"input file is not specified\n")     # msa.c:115-119
+    if util.ref_available("TSTA_msa") and util.cpu_has("avx512bw"):
+        ref = subprocess.run([os.path.join(util.REF_DIR, "TSTA_msa")], capture_output=True, timeout=60)
+        assert ours.stdout == ref.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [i for i, g in enumerate(GOLDEN) if g["kind"] == "example" or i % 4 == 0])
+def test_msa_cli_on_gpu(tmp_path, idx):
+    c = GOLDEN[idx]
+    sc = c["scoring"]
+    out = str(tmp_path / "out.txt")
+    r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O",
+                        str(sc["O"]), "-T", "4", "-i", input_path(c, tmp_path), "-o", out], capture_output=True, timeout=600)
+    check(c, r, out)

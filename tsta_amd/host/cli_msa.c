@@ -1,0 +1,67 @@
+/* cli_msa.c — drop-in for the reference's TSTA_msa executable (msa/msa.c:62-151): same flags, defaults, stderr /
+ * stdout lines and output-file bytes.  The sequence-vs-graph DP fill of every step runs on the MI355X
+ * (tsta_poa_fill); graph fusion, topological sorting and the result writer are host C (poa_graph.c). */
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
+
+#include "../../include/tsta_engine.h"
+#include "msa_driver.h"
+
+static void print_usage(void)
+{   /* the reference's help text, byte for byte (msa.c:62-73) */
+    printf("-M                      the sorce of match [default: 2]\n");
+    printf("-X                      the sorce of dismatch [default: -5]\n");
+    printf("-E                      the sorce of extend-gap [default: -2]\n");
+    printf("-O                      the sorce of open-gap [default: -4]\n");
+    printf("-T                      the number of threads [default: 10]\n");
+    printf("-W                      the width of block(Multiplication of simd data width) [default: 16]\n");
+    printf("-i                      the input sequence(fasta format)\n");
+    printf("-o                      the output file [default: output.txt]\n");
+    printf("example:\n./TSTA_msa -i seq.fa -o output.txt\n");
+}
+
+typedef struct gpu_ctx { tsta_engine* eng; tsta_params prm; } gpu_ctx;
+
+static int gpu_fill(void* vctx, int n_nodes, const int32_t* pred_off, const int32_t* pred, const uint8_t* base,
+                    const uint8_t* is_sink, const uint8_t* seq, int32_t n, int8_t* source, int8_t* esource,
+                    int8_t* fsource, int32_t* lastscore)
+{
+    gpu_ctx* c = (gpu_ctx*)vctx;
+    tsta_dag_csr dag = { n_nodes, pred_off, pred, base, is_sink };
+    int32_t best = -1;
+    int rc = tsta_poa_fill(c->eng, &c->prm, &dag, seq, n, source, esource, fsource, lastscore, &best);
+    if (rc != TSTA_OK) fprintf(stderr, "tsta_poa_fill: %s: %s\n", tsta_strerror(rc), tsta_last_error(c->eng));
+    return rc;
+}
+
+int main(int argc, char* argv[])
+{
+    gpu_ctx ctx = { NULL, { 2, -5, -2, -4 } };
+    const char *input = NULL, *output = "output.txt";
+    int c;
+    while ((c = getopt(argc, argv, "M:X:E:O:T:W:i:o:")) != -1) {
+        switch (c) {
+            case 'M': ctx.prm.M = atoi(optarg); break;
+            case 'X': ctx.prm.X = atoi(optarg); break;
+            case 'E': ctx.prm.E = atoi(optarg); break;
+            case 'O': ctx.prm.O = atoi(optarg); break;
+            case 'T': break;
+            case 'W': break;
+            case 'i': input = optarg; break;
+            case 'o': output = optarg; break;
+            default: print_usage(); return 0;                          /* msa.c:109-111 */
+        }
+    }
+    if (input == NULL) {                                             /* msa.c:115-119 */
+        printf("input file is not specified\n");
+        print_usage();
+        return 0;
+    }
+    const char* dev = getenv("TSTA_DEVICE");
+    int rc = tsta_engine_create(dev ? atoi(dev) : 0, &ctx.eng);
+    if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
+    rc = msa_run(input, output, gpu_fill, &ctx);
+    tsta_engine_destroy(ctx.eng);
+    return rc ? 1 : 0;
+}

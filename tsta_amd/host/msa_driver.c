@@ -1,0 +1,37 @@
+#include "msa_driver.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "fasta.h"
+
+int msa_run(const char* input, const char* output, pg_fill_fn fill, void* ctx)
+{
+    fasta_file* f = fasta_read(input, 0);
+    const int N = (int)f->count;
+    fprintf(stderr, "seq_num: %d\n", N);                                   /* msa.c:47 */
+    if (N == 0) { fasta_free(f); return 0; }
+    pg_graph* g = pg_build_init(f->seqs[0].data, N);                       /* msa.c:128 */
+    int rc = 0;
+    for (int i = 1; i < N - 1 && rc == 0; i++) {                           /* msa.c:130-137 */
+        rc = pg_align_and_fuse(g, f->seqs[i].data, i, fill, ctx);
+        if (rc) break;
+        pg_sort(g, 0);
+        if (i % 100 == 0) printf("\r[%d/%d]", i, N);
+    }
+    if (rc == 0) {
+        printf("\r[%d/%d]", N, N);
+        printf("\n");
+        fflush(stdout);
+        rc = pg_align_and_fuse(g, f->seqs[N - 1].data, N - 1, fill, ctx);   /* msa.c:140 (N == 1: S[0] against its own chain) */
+    }
+    if (rc == 0) {
+        pg_sort(g, 1);                                                     /* msa.c:141 */
+        FILE* res = fopen(output, "w");
+        if (!res) { fprintf(stderr, "cannot open %s\n", output); rc = 1; }
+        else { pg_write_result(g, N, res); fclose(res); }
+    }
+    pg_free(g);
+    fasta_free(f);
+    return rc;
+}
