@@ -15,16 +15,16 @@ __global__ __launch_bounds__(256) void k_pstep(unsigned long long* out, const un
 {
     const int lane = threadIdx.x & 63;
     PLane<R> s;
-    for (int k = 0; k < R; ++k) { s.hm[k] = init[lane + 64 * k]; s.fb[k] = init[lane + 64 * (k + R)]; s.bch[k] = init[lane + 64 * (k + 2 * R)] & 0xff00ff00u; }
-    s.hdm = init[lane]; s.hbot = init[lane + 1]; s.ebot = init[lane + 2]; s.cch = 0; s.th = init[lane + 3]; s.te = init[lane + 4];
+    for (int k = 0; k < R; ++k) { s.hl[k] = init[lane + 64 * k]; s.fb[k] = init[lane + 64 * (k + R)]; s.bch[k] = init[lane + 64 * (k + 2 * R)] & 0xff00ff00u; }
+    s.hd = init[lane]; s.hbot = init[lane + 1]; s.ebot = init[lane + 2]; s.cch = 0; s.th = init[lane + 3]; s.te = init[lane + 4];
     s.ach = init[lane + 5] & 0xff00ff00u; s.sh = 0; s.se = 0; s.mx = 0;
     pe = in_vgpr(pe); po = in_vgpr(po); pm = in_vgpr(pm); pmx = in_vgpr(pmx);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
-        if (VARIANT == 0) pstep<R, false, false>(s, i, lane, 1 << 30, R, pe, po, pm, pmx);
+        if (VARIANT == 0) pstep<R, false, false>(s, i, lane, 1 << 30, R, pe, po, pm, pmx, pe + pm);
         else {
             // no cross-lane traffic: isolates the DPP cost
-            unsigned d = s.hdm, h = 0, eu = s.ebot;
+            unsigned d = s.hd, h = 0, eu = s.ebot;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const unsigned e = eu - pe, f = s.fb[k] - pe, x = s.cch ^ s.bch[k];
@@ -32,14 +32,14 @@ __global__ __launch_bounds__(256) void k_pstep(unsigned long long* out, const un
                 h = pkmax(pkmax(dg, e), f);
                 const unsigned g = h - po;
                 const unsigned eb = pkmax(e, g), fbn = pkmax(f, g);
-                d = s.hm[k]; s.hm[k] = h + pm; s.fb[k] = fbn; s.mx = pkmax(s.mx, h); eu = eb;
+                d = s.hl[k]; s.hl[k] = h + pm; s.fb[k] = fbn; s.mx = pkmax(s.mx, h); eu = eb;
             }
-            s.hbot = h; s.ebot = eu; s.hdm = h + pm; s.cch += 0x01000100u;
+            s.hbot = h; s.ebot = eu; s.hd = h + pm; s.cch += 0x01000100u;
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned acc = s.mx ^ s.hbot ^ s.ebot ^ s.sh ^ s.se;
-    for (int k = 0; k < R; ++k) acc ^= s.hm[k] ^ s.fb[k];
+    for (int k = 0; k < R; ++k) acc ^= s.hl[k] ^ s.fb[k];
     if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
     if (acc == 0x12345678u) out[0] = 0;
 }

@@ -43,7 +43,7 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples)
     if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
     if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
     const int64_t U = std::max(std::max(p.M, p.X), 0) - (int64_t)p.O - (int64_t)p.E;
-    auto fits = [&](int R) { return (64LL * R + 192) * U - 2LL * p.O - p.E + p.M < 28000; };
+    auto fits = [&](int R) { return (64LL * R + 192) * U - 2LL * p.O - p.E + 130LL * p.M < 28000; };   // +128*M: column-shifted frame
     if (mode == 8) return fits(8) ? 8 : 0;
     if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
     if (fits(16)) return 16;
@@ -68,7 +68,10 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
 
     // ---- packed-int16 kernel (K1p) for couples of equal-geometry pairs, when the scoring fits 16-bit lanes
-    const int Rp = tsta::psa_packed_rows_per_lane(*p, n_pairs / 2);
+    // one wave nearly saturates a SIMD, so packing two pairs per wave only pays once there are more
+    // pairs than SIMDs; below that the int32 kernel keeps every SIMD busy with one pair each
+    const bool enough = n_pairs > (int64_t)e->n_cu * 4;
+    const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2) : 0;
     const int64_t couples = Rp ? n_pairs / 2 : 0;
     int64_t pblocks = 0;
     if (couples) {

@@ -39,16 +39,22 @@ constexpr int kNegInfP = -(1 << 30);
 
 template <int R>
 struct PLane {
-    unsigned hm[R];    // H(row k, previous column) + M        (biased, packed A|B)
-    unsigned fb[R];    // Fbar(row k, previous column)
+    unsigned hl[R];    // H'(row k, previous column)           (biased, packed A|B; H' = H - column*M, see pstep)
+    unsigned fb[R];    // Fbar'(row k, previous column)
     unsigned bch[R];   // row characters << 8 in each half
-    unsigned hdm;      // H(row above first row, previous column) + M
+    unsigned hd;       // H'(row above first row, previous column)
     unsigned hbot, ebot, cch, th, te, ach, sh, se, mx;
+    unsigned joff;     // (column of this step - (t0 - 63)) * M in both halves: turns H' back into H for the running max
 };
 
+// All scores are kept in the column-shifted frame  H'(i,j) = H(i,j) - j*M  (same for E, F, Ebar, Fbar).  The
+// diagonal term then needs no "+M":  D' = H'(i-1,j-1) - (match ? 0 : M-X);  the vertical gap is unchanged
+// (E' = Ebar'(i-1,j) - |E|, same column) and the horizontal gap pays the shift:  F' = Fbar'(i,j-1) - (|E|+M).
+// That removes one add per cell; the price is one add + one max per STEP to feed the running max in the H frame.
 template <int R, bool PRED, bool PARTIAL>
 __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nvalid,
-                                      const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx)
+                                      const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
+                                      const unsigned pf)
 {
     s.cch = ushr1(s.ach, s.cch);
     const unsigned hu = ushr1(s.th, s.hbot);
@@ -60,47 +66,53 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
     s.ach = ushl1(s.ach, s.ach);
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
-    unsigned d = s.hdm;
+    unsigned d = s.hd;
     unsigned h = 0;
+    unsigned m = 0;                                     // max of this step's H' over the lane's rows
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const unsigned e = eu - pe;                      // E = Ebar(up) + E          (v_sub_u32 on both halves)
-        const unsigned f = s.fb[k] - pe;                 // F = Fbar(left) + E
+        const unsigned e = eu - pe;                      // E' = Ebar'(up) - |E|        (v_sub_u32 on both halves)
+        const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)
         const unsigned x = s.cch ^ s.bch[k];             // 0 iff characters equal, else >= 256 per half
         const unsigned tt = pkmin(x, pmx);               // 0 or M-X
-        const unsigned dg = d - tt;                      // (Hdiag + M) - (match ? 0 : M-X)
+        const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
         h = pkmax(pkmax(dg, e), f);
-        const unsigned g = h - po;                       // H + O
+        const unsigned g = h - po;                       // H' + O
         const unsigned eb = pkmax(e, g);
         const unsigned fbn = pkmax(f, g);
-        d = s.hm[k];
+        d = s.hl[k];
         unsigned hv = h;
         if (PARTIAL) hv = (k < nvalid) ? hv : 0u;
         if (PRED) {
-            s.hm[k] = act ? h + pm : s.hm[k];
+            s.hl[k] = act ? h : s.hl[k];
             s.fb[k] = act ? fbn : s.fb[k];
-            hv = act ? hv : 0u;
         } else {
-            s.hm[k] = h + pm;
+            s.hl[k] = h;
             s.fb[k] = fbn;
         }
-        s.mx = pkmax(s.mx, hv);
+        m = (k == 0) ? hv : pkmax(m, hv);
         eu = eb;
     }
     s.hbot = h;
     s.ebot = eu;
-    if (PRED) s.hdm = act ? hu + pm : s.hdm; else s.hdm = hu + pm;
+    if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
+    // running max in the H frame: H - anchor = H' + (column - anchor column)*M ; joff >= 0, no carry across halves
+    unsigned cand = m + s.joff;
+    if (PRED) cand = act ? cand : 0u;
+    if (PARTIAL) cand = (nvalid > 0) ? cand : 0u;
+    s.mx = pkmax(s.mx, cand);
+    s.joff += pm;
 }
 
 __device__ __forceinline__ int hcol0p(int i, int E, int O) { return i == 0 ? 0 : O + i * E; }
 
-struct PairAcc { int baseA, baseB, mxA, mxB; };
+struct PairAcc { int baseA, baseB, mxA, mxB, ancA, ancB; };   // base: anchor of the H' frame; anc: anchor of the running max (H frame)
 
 template <int R>
 __device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc)
 {
-    acc.mxA = max(acc.mxA, (int)(s.mx & 0xffffu) + acc.baseA - kBias);
-    acc.mxB = max(acc.mxB, (int)(s.mx >> 16) + acc.baseB - kBias);
+    if ((s.mx & 0xffffu) != 0u) acc.mxA = max(acc.mxA, (int)(s.mx & 0xffffu) + acc.ancA - kBias);
+    if ((s.mx >> 16) != 0u)     acc.mxB = max(acc.mxB, (int)(s.mx >> 16) + acc.ancB - kBias);
     s.mx = 0u;
 }
 
@@ -116,19 +128,20 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
                                       const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s)
 {
     const unsigned pe = in_vgpr(pe_s), po = in_vgpr(po_s), pm = in_vgpr(pm_s), pmx = in_vgpr(pmx_s);
+    const unsigned pf = pe + pm;                   // |E| + M: the horizontal gap pays the column shift of the H' frame
     PLane<R> s;
     const int i0 = band_row0 + lane * R;
     const int nvalid = m - i0;
-    // anchor: top row of the band at the first column
+    // anchor of the H' frame: the band's top row at the first column (H' = H - (column index + 1) * M)
     int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
     int naA = 0, naB = 0;
     { const int l0 = opaque(lane); if (l0 < n) { ntA = rowA[l0]; ntB = rowB[l0]; naA = aA[l0]; naB = aB[l0]; } }
-    acc.baseA = __builtin_amdgcn_readfirstlane(ntA.x);
-    acc.baseB = __builtin_amdgcn_readfirstlane(ntB.x);
+    acc.baseA = __builtin_amdgcn_readfirstlane(ntA.x) - M;
+    acc.baseB = __builtin_amdgcn_readfirstlane(ntB.x) - M;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const int hk = hcol0p(i0 + 1 + k, E, O);
-        s.hm[k] = pack2(hk + M - acc.baseA + kBias, hk + M - acc.baseB + kBias);
+        const int hk = hcol0p(i0 + 1 + k, E, O);   // column 0: H' = H
+        s.hl[k] = pack2(hk - acc.baseA + kBias, hk - acc.baseB + kBias);
         s.fb[k] = pack2(hk + O - acc.baseA + kBias, hk + O - acc.baseB + kBias);
         const int cA = (i0 + k < m) ? ((int)bA[i0 + k] << 8) : 0x1ff;
         const int cB = (i0 + k < m) ? ((int)bB[i0 + k] << 8) : 0x1ff;
@@ -136,7 +149,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     }
     {
         const int hd = hcol0p(i0, E, O);
-        s.hdm = pack2(hd + M - acc.baseA + kBias, hd + M - acc.baseB + kBias);
+        s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
     }
     s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.sh = s.hbot; s.se = s.hbot; s.mx = 0u;
 
@@ -146,29 +159,40 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         if (t0 > 0 && t0 < n) {
             // re-anchor both pairs to the band's top row at column t0
             fold_max<R>(s, acc);
-            const int nbA = __builtin_amdgcn_readfirstlane(ntA.x), nbB = __builtin_amdgcn_readfirstlane(ntB.x);
+            const int nbA = __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M;
+            const int nbB = __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M;
             const unsigned pd = pack2(nbA - acc.baseA, nbB - acc.baseB);
             acc.baseA = nbA; acc.baseB = nbB;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { s.hm[k] = pksub(s.hm[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
-            s.hdm = pksub(s.hdm, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
+            for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
+            s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
+        } else if (t0 >= n) {
+            fold_max<R>(s, acc);                   // last (drain) block keeps the previous anchor
         }
-        s.th = pack2(ntA.x - acc.baseA + kBias, ntB.x - acc.baseB + kBias);
-        s.te = pack2(ntA.y - acc.baseA + kBias, ntB.y - acc.baseB + kBias);
+        // running-max anchor of this block: column index t0-63 in the H frame
+        acc.ancA = acc.baseA + (t0 - 62) * M;
+        acc.ancB = acc.baseB + (t0 - 62) * M;
+        s.joff = pack2((63 - ln) * M, (63 - ln) * M);
+        {
+            const int sh_m = (t0 + ln + 1) * M;    // column shift of this lane's top-row entry
+            s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
+            s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
+        }
         s.ach = pack2(naA << 8, naB << 8);
         const int cn = t0 + 64 + ln;
         if (cn < n) { ntA = rowA[cn]; ntB = rowB[cn]; naA = aA[cn]; naB = aB[cn]; }
         if (t0 >= 64 && t0 + 63 < n) {
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx);
+            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx, pf);
         } else {
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx);
+            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx, pf);
         }
         const int cs = t0 - 64 + opaque(lane);
         if (!PARTIAL && cs >= 0 && cs < n) {
-            rowA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA, (int)(s.se & 0xffffu) - kBias + acc.baseA);
-            rowB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB, (int)(s.se >> 16) - kBias + acc.baseB);
+            const int sh_m = (cs + 1) * M;
+            rowA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
+            rowB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
         }
     }
     fold_max<R>(s, acc);
@@ -185,7 +209,7 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
         rowB[c] = make_int2(h, h + O);
     }
     wave_mem_sync();
-    PairAcc acc; acc.baseA = 0; acc.baseB = 0; acc.mxA = kNegInfP; acc.mxB = kNegInfP;
+    PairAcc acc; acc.baseA = 0; acc.baseB = 0; acc.ancA = 0; acc.ancB = 0; acc.mxA = kNegInfP; acc.mxB = kNegInfP;
     constexpr int BAND = 64 * R;
     int r0 = 0;
     for (; r0 + BAND <= m; r0 += BAND) {
