@@ -80,16 +80,13 @@ def test_full_size_100k_properties(eng):
     assert util.alignment_score(ra, rb) == oend
 
 
-def test_rows_per_lane_4_variant_in_subprocess():
-    # the R=4 instantiation of the trace kernels (default is R=2) is selected by an env knob read once per process
-    import subprocess, sys, os
-    code = ("import numpy as np, tsta_amd\nfrom tests import util\n"
-            "e = tsta_amd.Engine(0)\n"
-            "for (l1, l2) in [(300, 257), (1500, 1400), (5000, 4900)]:\n"
-            "    a = util.random_dna(l1 + l2, l1); b = util.mutate(a, l1, 0.1)[:l2]\n"
-            "    got = e.psa_align(a, b); o = util.oracle_align(a, b)\n"
-            "    assert got == (o[0], o[2], o[3]), (l1, l2)\n"
-            "print('ok')\n")
-    env = dict(os.environ, TSTA_TRACE_R="4", TSTA_TRACE_T="128", PYTHONPATH=util.ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=util.ROOT)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+def test_rows_per_lane_4_variant(eng):
+    # the R=4 instantiation of the trace kernels and a longer tile (defaults: R=2, T=64)
+    try:
+        eng.set_option("trace_rows", 4); eng.set_option("trace_tile", 128)
+        for (l1, l2) in [(300, 257), (1500, 1400), (5000, 4900)]:
+            a = util.random_dna(l1 + l2, l1); b = util.mutate(a, l1, 0.1)[:l2]
+            got = eng.psa_align(a, b); o = util.oracle_align(a, b)
+            assert got == (o[0], o[2], o[3]), (l1, l2)
+    finally:
+        eng.set_option("trace_rows", 0); eng.set_option("trace_tile", 0)

@@ -131,9 +131,14 @@ def test_packed_couples_equal_geometry(eng, scoring):
             else:
                 b = _fixed_len(a[::-1].copy(), m, 5)                                      # reversed: poor alignment
             pairs.append((a, b) if j == 0 else (b, a))                                    # second member swapped
-    got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
     want = util.oracle_maxscore_batch(pairs, **scoring)
-    assert np.array_equal(got, want), (scoring, got.tolist(), want.tolist())
+    try:
+        for mode in (16, 8, 0):          # forced packed R=16 / R=8 (falls back when the scoring does not fit) / int32 only
+            eng.set_option("psa_packed", mode)
+            got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+            assert np.array_equal(got, want), (mode, scoring, got.tolist(), want.tolist())
+    finally:
+        eng.set_option("psa_packed", -1)
 
 
 def test_packed_adversarial_content(eng):
@@ -146,10 +151,14 @@ def test_packed_adversarial_content(eng):
              (lc, lc.copy()), (lc, np.roll(lc, 1)),
              (np.concatenate([x[:3000], A[:3000]]), np.concatenate([A[:3000], x[:3000]])),   # long forced gaps
              (x, np.concatenate([x[3000:], x[:3000]]))]
-    for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7)):
-        got = eng.psa_score_batch(pairs, tsta_amd.Params(**sc))
-        want = util.oracle_maxscore_batch(pairs, **sc)
-        assert np.array_equal(got, want), (sc, got.tolist(), want.tolist())
+    try:
+        eng.set_option("psa_packed", 16)
+        for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7)):
+            got = eng.psa_score_batch(pairs, tsta_amd.Params(**sc))
+            want = util.oracle_maxscore_batch(pairs, **sc)
+            assert np.array_equal(got, want), (sc, got.tolist(), want.tolist())
+    finally:
+        eng.set_option("psa_packed", -1)
 
 
 def test_packed_and_int32_paths_agree_at_50k(eng, monkeypatch):
@@ -157,5 +166,31 @@ def test_packed_and_int32_paths_agree_at_50k(eng, monkeypatch):
     x = util.random_dna(4242, 50_000)
     y = _fixed_len(util.mutate(x, 4243, 0.05), 50_000, 1)
     z = _fixed_len(util.mutate(x, 4244, 0.15), 50_000, 2)
-    got = eng.psa_score_batch([(x, y), (x, z)])
-    assert got[0] == util.oracle_maxscore(x, y) and got[1] == util.oracle_maxscore(x, z)
+    want = [util.oracle_maxscore(x, y), util.oracle_maxscore(x, z)]
+    try:
+        for mode in (16, 0):
+            eng.set_option("psa_packed", mode)
+            got = eng.psa_score_batch([(x, y), (x, z)])
+            assert got.tolist() == want, mode
+    finally:
+        eng.set_option("psa_packed", -1)
+
+
+def test_auto_mode_large_batch_uses_both_kernels(eng):
+    # > 1024 pairs: auto mode packs the equal-geometry couples and leaves the rest to the int32 kernel in the same call
+    pairs = []
+    for i in range(1300):
+        n = 200 + (i // 2) % 7 * 31                     # couples (2c, 2c+1) share n; every 5th couple is broken on purpose
+        a = util.random_dna(50_000 + i, n)
+        b = _fixed_len(util.mutate(a, 60_000 + i, 0.1), n - (3 if i % 10 == 9 else 0), i)
+        pairs.append((a, b))
+    got = eng.psa_score_batch(pairs)
+    want = util.oracle_maxscore_batch(pairs)
+    assert np.array_equal(got, want)
+
+
+def test_set_option_rejects_unknown(eng):
+    with pytest.raises(tsta_amd.TstaError):
+        eng.set_option("no_such_knob", 1)
+    with pytest.raises(tsta_amd.TstaError):
+        eng.set_option("psa_packed", 5)

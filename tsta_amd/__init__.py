@@ -18,7 +18,7 @@ lib_path = os.path.join(_HERE, "lib", "libtsta_hip.so")
 EXPORTED_SYMBOLS = [
     "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
-    "tsta_last_kernel_ms",
+    "tsta_last_kernel_ms", "tsta_engine_set_option",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
         L.tsta_engine_create.restype = C.c_int; L.tsta_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.tsta_engine_destroy.restype = None; L.tsta_engine_destroy.argtypes = [vp]
         L.tsta_free.restype = None; L.tsta_free.argtypes = [vp]
+        L.tsta_engine_set_option.restype = C.c_int; L.tsta_engine_set_option.argtypes = [vp, C.c_char_p, i64]
         L.tsta_psa_score_batch.restype = C.c_int
         L.tsta_psa_score_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
         L.tsta_psa_score_batch_dev.restype = C.c_int
@@ -121,6 +122,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key, value):
+        """Tuning knob (see tsta_engine_set_option in include/tsta_engine.h); results never depend on it."""
+        self._check(lib().tsta_engine_set_option(self._h, key.encode(), int(value)), "tsta_engine_set_option(%s)" % key)
 
     def _check(self, rc, what):
         if rc != 0:

@@ -21,6 +21,9 @@ struct Engine {
     int         n_launches = 0;
     char        err[512] = {0};
 
+    // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0;
+
     DevBuf counter;      // ticket counters / flags (zeroed per launch)
     DevBuf rows;         // PSA per-wave boundary rows
     DevBuf in_seqs;      // staging for host-pointer entry points

@@ -87,6 +87,10 @@ int tsta_engine_create(int device, tsta_engine** out)
     Engine* e = new (std::nothrow) Engine();
     if (!e) return TSTA_ERR_OOM;
     e->device = device;
+    if (const char* v = getenv("TSTA_PSA_PACKED")) e->opt_psa_packed = atoi(v);
+    if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
+    if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
+    if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
     int rc;
     hipDeviceProp_t prop;
     if ((rc = e->check(hipSetDevice(device), "hipSetDevice")) != TSTA_OK ||
@@ -140,6 +144,18 @@ void tsta_engine_destroy(tsta_engine* eng)
 }
 
 void tsta_free(void* p) { free(p); }
+
+int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
+{
+    if (!eng || !key) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    const int v = (int)value;
+    if (!strcmp(key, "psa_packed") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_packed = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
+    return TSTA_ERR_INVALID_ARG;
+}
 
 int tsta_last_kernel_ms(tsta_engine* eng, float* ms, int32_t* n_launches)
 {

@@ -16,15 +16,9 @@ namespace tsta {
 
 // Rows per lane (band height = 64*R).  Larger R amortises the per-step lane hand-off over more cells but
 // leaves lanes idle when the row sequence is shorter than a band.
-static int psa_rows_per_lane(int32_t max_len)
+static int psa_rows_per_lane(int32_t max_len, int forced)
 {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* s = getenv("TSTA_PSA_R");        // tuning knob for experiments: 4, 8 or 16
-        int v = s ? atoi(s) : 0;
-        forced = (v == 4 || v == 8 || v == 16) ? v : 0;
-    }
-    if (forced) return forced;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
     return max_len >= 4096 ? 16 : (max_len >= 1024 ? 8 : 4);
 }
 
@@ -32,13 +26,8 @@ static int psa_rows_per_lane(int32_t max_len)
 // does not fit: the kernel needs E,O <= 0 <= M, 0 <= M-X <= 255 and every value in flight within the 16-bit
 // window around the per-pair base: (64R+192)*U + |O+E| + |O| + M < 28000, U = max(M,X,0)+|O|+|E| bounding the
 // score difference of adjacent cells.
-static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples)
+static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int mode)   // mode: -1 auto, 0 never, 8/16 forced
 {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* s = getenv("TSTA_PSA_PACKED");   // tuning/debug knob: 0 = never, 8 / 16 = force rows per lane
-        mode = s ? atoi(s) : 1;
-    }
     if (mode == 0 || couples < 1) return 0;
     if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
     if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
@@ -70,8 +59,8 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     // ---- packed-int16 kernel (K1p) for couples of equal-geometry pairs, when the scoring fits 16-bit lanes
     // one wave nearly saturates a SIMD, so packing two pairs per wave only pays once there are more
     // pairs than SIMDs; below that the int32 kernel keeps every SIMD busy with one pair each
-    const bool enough = n_pairs > (int64_t)e->n_cu * 4;
-    const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2) : 0;
+    const bool enough = n_pairs > (int64_t)e->n_cu * 4 || e->opt_psa_packed > 0;
+    const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2, e->opt_psa_packed) : 0;
     const int64_t couples = Rp ? n_pairs / 2 : 0;
     int64_t pblocks = 0;
     if (couples) {
@@ -79,7 +68,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         if (pblocks < 1) pblocks = 1;
     }
     // ---- int32 kernel (K1) for everything else
-    const int R = tsta::psa_rows_per_lane(max_len);
+    const int R = tsta::psa_rows_per_lane(max_len, e->opt_psa_rows);
     const int per_cu = tsta::psa_score_blocks_per_cu(R);
     int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, (int64_t)e->n_cu * per_cu);
     if (blocks < 1) blocks = 1;

@@ -340,8 +340,7 @@ static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, c
                      int32_t* maxscore, int32_t* end_score, std::vector<uint8_t>& ops, int& fi, int& fj)
 {
     constexpr int NS = TraceCfg<R>::NS;
-    static const int T_env = getenv("TSTA_TRACE_T") ? atoi(getenv("TSTA_TRACE_T")) : 0;    // tuning knob (multiple of 64)
-    const int T = (T_env >= 64 && T_env % 64 == 0) ? T_env : 64;
+    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 64;   // knob "trace_tile"
     const int W = (m + 64 * R - 1) / (64 * R);
     const int S_total = (n + 64 + 63) / 64 * 64;
     const int64_t row_stride = S_total + 64;
@@ -429,7 +428,7 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
     int32_t ms = -100, es = 0;
     if (m > 0 && n > 0) {
         // rows per lane: small bands expose more concurrent bands of the single pair
-        static const int R_env = getenv("TSTA_TRACE_R") ? atoi(getenv("TSTA_TRACE_R")) : 0;   // tuning knob: 2 or 4
+        const int R_env = e->opt_trace_rows;                                                    // knob "trace_rows"
         const int Rsel = (R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
         if (Rsel == 4) rc = run_align<4>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
         else           rc = run_align<2>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
