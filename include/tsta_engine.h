@@ -51,6 +51,7 @@ void tsta_free(void* p);                                   /* frees host buffers
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline
+ *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */
 int  tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value);
 

@@ -69,6 +69,23 @@ def test_random_dags_vs_oracle(eng, seed, V, max_pred, n):
             assert np.array_equal(g, w)
 
 
+def test_four_columns_per_lane_variant(eng):
+    # default for n <= 16384 is 2 columns per lane; exercise the 256-column-tile instantiation too
+    try:
+        eng.set_option("poa_cols", 4)
+        for path in FIXTURES[:6] + FIXTURES[-3:]:
+            z, sc = load(path)
+            best, last, src, es, fs = eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"],
+                                                   tsta_amd.Params(**sc))
+            check_against_fixture(z, best, last, src, es, fs)
+        pred_off, pred, base, is_sink, seq = random_dag(5, 700, 12, 8193)
+        got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+        want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
+    finally:
+        eng.set_option("poa_cols", 0)
+
+
 def test_rejects_bad_dags(eng):
     base = np.frombuffer(b"ACG", np.uint8); sink = np.array([0, 0, 1], np.uint8); seq = util.random_dna(1, 10)
     with pytest.raises(tsta_amd.TstaError):       # predecessor not earlier in topological order

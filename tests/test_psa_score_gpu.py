@@ -194,3 +194,48 @@ def test_set_option_rejects_unknown(eng):
         eng.set_option("no_such_knob", 1)
     with pytest.raises(tsta_amd.TstaError):
         eng.set_option("psa_packed", 5)
+
+
+def test_config2_full_size_all_pairs(eng):
+    # BASELINE config #2 at full size: 1024 pairs of 5 kbp x 5 kbp random DNA, every score checked against the oracle
+    pairs = [(util.random_dna(2 * p, 5000), util.random_dna(2 * p + 1, 5000)) for p in range(1024)]
+    got = eng.psa_score_batch(pairs)
+    want = util.oracle_maxscore_batch(pairs, threads=os.cpu_count() or 8)
+    assert np.array_equal(got, want)
+
+
+def test_config5_shape_sample(eng):
+    # BASELINE config #5 shape (50 kbp x 50 kbp, packed kernel in auto mode since > 1024 pairs): 1100 pairs on the GPU,
+    # a sample of them against the O(n)-memory oracle, plus an in-batch duplicate as a size-independent consistency check
+    base = [(util.random_dna(7000 + 2 * p, 50_000), util.random_dna(7001 + 2 * p, 50_000)) for p in range(8)]
+    x = util.random_dna(4242, 50_000)
+    rel = (x, _fixed_len(util.mutate(x, 4243, 0.05), 50_000, 1))
+    pairs = [base[p % 8] for p in range(1098)] + [rel, rel]
+    got = eng.psa_score_batch(pairs)
+    for p in range(8):
+        assert np.all(got[p:1098:8] == got[p])                     # identical inputs, identical outputs in every slot
+    for p in (0, 5):
+        assert got[p] == util.oracle_maxscore(*base[p])
+    assert got[1098] == got[1099] == util.oracle_maxscore(*rel)
+
+
+def test_error_paths(eng):
+    import ctypes as C
+    L = tsta_amd.lib()
+    prm = tsta_amd.Params()
+    one = np.zeros(1, dtype=np.int64); l = np.array([5], dtype=np.int32); out = np.zeros(1, dtype=np.int32)
+    seq = util.random_dna(1, 8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    # sequence range outside the buffer
+    off_bad = np.array([6], dtype=np.int64)
+    assert L.tsta_psa_score_batch(eng._h, C.byref(prm), 1, p(seq), 8, p(off_bad), p(l), p(one), p(l), p(out)) == -1
+    # null pointers / negative counts
+    assert L.tsta_psa_score_batch(eng._h, C.byref(prm), 1, None, 8, p(one), p(l), p(one), p(l), p(out)) == -1
+    assert L.tsta_psa_score_batch(eng._h, C.byref(prm), -1, p(seq), 8, p(one), p(l), p(one), p(l), p(out)) == -1
+    assert L.tsta_psa_score_batch(None, C.byref(prm), 1, p(seq), 8, p(one), p(l), p(one), p(l), p(out)) == -1
+    ms = C.c_int32(); ra = C.c_void_p(); rb = C.c_void_p(); ln = C.c_int64()
+    # longer than the supported maximum (2^24)
+    assert L.tsta_psa_align(eng._h, C.byref(prm), p(seq), (1 << 24) + 1, p(seq), 4, C.byref(ms), C.byref(ra), C.byref(rb),
+                            C.byref(ln)) == -5
+    assert L.tsta_psa_align(eng._h, C.byref(prm), p(seq), -3, p(seq), 4, C.byref(ms), C.byref(ra), C.byref(rb), C.byref(ln)) == -1
+    assert b"invalid" in L.tsta_strerror(-1)

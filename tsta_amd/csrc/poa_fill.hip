@@ -31,8 +31,7 @@
 namespace tsta {
 
 constexpr int kNeg = -1000000000;
-constexpr int KC = 4;                    // columns per lane
-constexpr int kCW = 64 * KC;             // columns per tile (one wave)
+// columns per lane KC = 4 (256-column tiles) or 2 (128-column tiles: more tiles in flight for short sequences)
 constexpr int kRB = 32;                  // graph nodes (rows) per tile; <= 64 (per-row side data lives one row per lane)
 
 struct PoaArgs {
@@ -45,6 +44,7 @@ struct PoaArgs {
     int* carry;                          // [V][nchunks+1]: Fbar entering chunk q of row r
     uint8_t* cflag;                      // [V][nchunks+1]: "F at the first column of chunk q is an open"
     int nchunks, nrb, d, q_lo;           // launch d runs the tiles (q, rb = d - q)
+    int kc;                              // columns per lane of this run (2 or 4)
     int8_t* source; int8_t* esource; int8_t* fsource; int64_t tpitch;   // [V][tpitch] device layout (tpitch mult. of 8)
     int* lastscore;                      // [V]
     int* best;                           // [0] = best sink
@@ -65,8 +65,10 @@ __global__ void poa_init_kernel(PoaArgs A)
 
 // One wave = one tile: kRB consecutive nodes (topological order) x kCW consecutive columns, rows in order,
 // KC columns per lane.  Tiles on the anti-diagonal q + rb = d are independent (launch d).
+template <int KC>
 __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
 {
+    constexpr int kCW = 64 * KC;
     const int lane = threadIdx.x;
     const int q = A.q_lo + blockIdx.x, rb = A.d - q;
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
@@ -157,10 +159,17 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                 const int* Hp = A.Hrow + (size_t)p * A.pitch + c0 + 3;     // H(p, c0 .. c0+KC)
                 const int* Ep = A.Erow + (size_t)p * A.pitch + c0;         // Eagg(p, c0+1 .. c0+KC)
                 hv[0] = Hp[0];
-                const int4 ha = *reinterpret_cast<const int4*>(Hp + 1);
-                const int4 ea = *reinterpret_cast<const int4*>(Ep);
-                hv[1] = ha.x; hv[2] = ha.y; hv[3] = ha.z; hv[4] = ha.w;
-                ev[0] = ea.x; ev[1] = ea.y; ev[2] = ea.z; ev[3] = ea.w;
+                if constexpr (KC == 4) {
+                    const int4 ha = *reinterpret_cast<const int4*>(Hp + 1);
+                    const int4 ea = *reinterpret_cast<const int4*>(Ep);
+                    hv[1] = ha.x; hv[2] = ha.y; hv[3] = ha.z; hv[4] = ha.w;
+                    ev[0] = ea.x; ev[1] = ea.y; ev[2] = ea.z; ev[3] = ea.w;
+                } else {
+                    const int2 ha = *reinterpret_cast<const int2*>(Hp + 1);
+                    const int2 ea = *reinterpret_cast<const int2*>(Ep);
+                    hv[1] = ha.x; hv[2] = ha.y;
+                    ev[0] = ea.x; ev[1] = ea.y;
+                }
             }
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
@@ -227,12 +236,22 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                 w2 |= (unsigned)(uint8_t)ecode << (8 * k);
                 w3 |= (unsigned)(uint8_t)fcode << (8 * k);
             }
-            *reinterpret_cast<int4*>(Hr + c0 + 4) = make_int4(hs[0], hs[1], hs[2], hs[3]);     // H(r, c0+1..c0+4)
-            *reinterpret_cast<int4*>(Er + c0) = make_int4(es[0], es[1], es[2], es[3]);
-            if (A.source) {
-                *reinterpret_cast<unsigned*>(A.source + (size_t)r * A.tpitch + c0) = w1;
-                *reinterpret_cast<unsigned*>(A.esource + (size_t)r * A.tpitch + c0) = w2;
-                *reinterpret_cast<unsigned*>(A.fsource + (size_t)r * A.tpitch + c0) = w3;
+            if constexpr (KC == 4) {
+                *reinterpret_cast<int4*>(Hr + c0 + 4) = make_int4(hs[0], hs[1], hs[2], hs[3]);     // H(r, c0+1..c0+4)
+                *reinterpret_cast<int4*>(Er + c0) = make_int4(es[0], es[1], es[2], es[3]);
+                if (A.source) {
+                    *reinterpret_cast<unsigned*>(A.source + (size_t)r * A.tpitch + c0) = w1;
+                    *reinterpret_cast<unsigned*>(A.esource + (size_t)r * A.tpitch + c0) = w2;
+                    *reinterpret_cast<unsigned*>(A.fsource + (size_t)r * A.tpitch + c0) = w3;
+                }
+            } else {
+                *reinterpret_cast<int2*>(Hr + c0 + 4) = make_int2(hs[0], hs[1]);
+                *reinterpret_cast<int2*>(Er + c0) = make_int2(es[0], es[1]);
+                if (A.source) {
+                    *reinterpret_cast<unsigned short*>(A.source + (size_t)r * A.tpitch + c0) = (unsigned short)w1;
+                    *reinterpret_cast<unsigned short*>(A.esource + (size_t)r * A.tpitch + c0) = (unsigned short)w2;
+                    *reinterpret_cast<unsigned short*>(A.fsource + (size_t)r * A.tpitch + c0) = (unsigned short)w3;
+                }
             }
             if (c0 + KC >= n) {                              // owner of the last column
                 const int kl = n - 1 - c0;
@@ -295,9 +314,13 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
 
-    const int nchunks = (n + tsta::kCW - 1) / tsta::kCW, nrb = (V + tsta::kRB - 1) / tsta::kRB;
-    const int64_t pitch = ((int64_t)nchunks * tsta::kCW + 8 + 3) / 4 * 4 + 8;
-    const int64_t tpitch = (int64_t)nchunks * tsta::kCW;
+    // 4 columns per lane (256-column tiles) are cheaper per cell; 2 per lane put twice as many tiles in flight,
+    // which wins while the sequence is short enough that the tile wavefront is the limit
+    const int kc = (e->opt_poa_cols == 2 || e->opt_poa_cols == 4) ? e->opt_poa_cols : (n <= 16384 ? 2 : 4);
+    const int cw = 64 * kc;
+    const int nchunks = (n + cw - 1) / cw, nrb = (V + tsta::kRB - 1) / tsta::kRB;
+    const int64_t pitch = ((int64_t)nchunks * cw + 8 + 3) / 4 * 4 + 8;
+    const int64_t tpitch = ((int64_t)nchunks * cw + 7) / 8 * 8;
     const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 4 + (size_t)V * 2 + (size_t)n + 64;
     const size_t rows_bytes = (size_t)(V + 1) * pitch * sizeof(int);
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)")) ||
@@ -329,7 +352,7 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     A.tpitch = tpitch;
     A.carry = reinterpret_cast<int*>(e->scratch.p);
     A.cflag = reinterpret_cast<uint8_t*>(e->scratch2.p);
-    A.nchunks = nchunks; A.nrb = nrb;
+    A.nchunks = nchunks; A.nrb = nrb; A.kc = kc;
     A.source = want_trace ? reinterpret_cast<int8_t*>(e->trace.p) : nullptr;
     A.esource = want_trace ? A.source + (size_t)V * tpitch : nullptr;
     A.fsource = want_trace ? A.esource + (size_t)V * tpitch : nullptr;
@@ -343,7 +366,8 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     for (int d = 0; d < nchunks + nrb - 1; ++d) {            // tile anti-diagonals: q + rb = d
         const int q_lo = std::max(0, d - nrb + 1), q_hi = std::min(nchunks - 1, d);
         A.d = d; A.q_lo = q_lo;
-        hipLaunchKernelGGL(poa_tile_kernel, dim3(q_hi - q_lo + 1), dim3(64), 0, s, A);
+        if (kc == 2) hipLaunchKernelGGL(poa_tile_kernel<2>, dim3(q_hi - q_lo + 1), dim3(64), 0, s, A);
+        else         hipLaunchKernelGGL(poa_tile_kernel<4>, dim3(q_hi - q_lo + 1), dim3(64), 0, s, A);
         ++launches;
     }
     hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
