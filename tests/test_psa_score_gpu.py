@@ -153,7 +153,9 @@ def test_packed_adversarial_content(eng):
              (x, np.concatenate([x[3000:], x[:3000]]))]
     try:
         eng.set_option("psa_packed", 16)
-        for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7)):
+        # the last two sit just inside the 16-bit range bound of the packed kernel for R=16 and for R=8
+        for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7), dict(M=5, X=-4, E=-6, O=-8),
+                   dict(M=10, X=-9, E=-10, O=-12)):
             got = eng.psa_score_batch(pairs, tsta_amd.Params(**sc))
             want = util.oracle_maxscore_batch(pairs, **sc)
             assert np.array_equal(got, want), (sc, got.tolist(), want.tolist())

@@ -24,7 +24,7 @@ static int psa_rows_per_lane(int32_t max_len, int forced)
 
 // Packed-int16 kernel eligibility (psa_score_packed.hip): returns rows per lane (16 or 8), or 0 when the scoring
 // does not fit: the kernel needs E,O <= 0 <= M, 0 <= M-X <= 255 and every value in flight within the 16-bit
-// window around the per-pair base: (64R+192)*U + |O+E| + |O| + M < 28000, U = max(M,X,0)+|O|+|E| bounding the
+// window around the per-pair base: (64R+256)*U + |O+E| + |O| + 200*M < 28000, U = max(M,X,0)+|O|+|E| bounding the
 // score difference of adjacent cells.
 static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int mode)   // mode: -1 auto, 0 never, 8/16 forced
 {
@@ -32,7 +32,7 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int m
     if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
     if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
     const int64_t U = std::max(std::max(p.M, p.X), 0) - (int64_t)p.O - (int64_t)p.E;
-    auto fits = [&](int R) { return (64LL * R + 192) * U - 2LL * p.O - p.E + 130LL * p.M < 28000; };   // +128*M: column-shifted frame
+    auto fits = [&](int R) { return (64LL * R + 256) * U - 2LL * p.O - p.E + 200LL * p.M < 28000; };   // rows 64R + columns <= 192 (drain block) from the anchor; +M per column of the shifted frame
     if (mode == 8) return fits(8) ? 8 : 0;
     if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
     if (fits(16)) return 16;
