@@ -191,6 +191,18 @@ def test_auto_mode_large_batch_uses_both_kernels(eng):
     assert np.array_equal(got, want)
 
 
+def test_host_api_groups_equal_geometry(eng):
+    # the host-pointer form orders pairs by geometry so interleaved equal-geometry pairs are packed; output order is the caller's
+    pairs = []
+    for i in range(1500):
+        n = [300, 450, 300, 610][i % 4]
+        a = util.random_dna(80_000 + i, n)
+        pairs.append((a, _fixed_len(util.mutate(a, 81_000 + i, 0.08), n - (i % 4), i)) if i % 3 else (_fixed_len(a[::-1].copy(), n - (i % 4), 3), a))
+    got = eng.psa_score_batch(pairs)
+    want = util.oracle_maxscore_batch(pairs)
+    assert np.array_equal(got, want)
+
+
 def test_set_option_rejects_unknown(eng):
     with pytest.raises(tsta_amd.TstaError):
         eng.set_option("no_such_knob", 1)

@@ -155,6 +155,23 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     const size_t nb = (size_t)n_pairs;
+    // Order the pairs by oriented geometry (columns n, rows m) so that equal-geometry pairs sit next to each other and
+    // can share a wave in the packed kernel (couples are adjacent pairs); results are scattered back to the caller's order.
+    std::vector<int64_t> perm(nb);
+    for (size_t k = 0; k < nb; ++k) perm[k] = (int64_t)k;
+    auto key = [&](int64_t k) {
+        const int32_t a = len1[k], b = len2[k];
+        return ((uint64_t)(uint32_t)std::max(a, b) << 32) | (uint32_t)std::min(a, b);
+    };
+    bool sorted_already = true;
+    for (size_t k = 1; k < nb && sorted_already; ++k) sorted_already = key((int64_t)k - 1) <= key((int64_t)k);
+    if (!sorted_already) std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+    std::vector<int64_t> h_off(2 * nb);
+    std::vector<int32_t> h_len(2 * nb);
+    for (size_t k = 0; k < nb; ++k) {
+        h_off[k] = off1[perm[k]]; h_off[nb + k] = off2[perm[k]];
+        h_len[k] = len1[perm[k]]; h_len[nb + k] = len2[perm[k]];
+    }
     const size_t meta_bytes = nb * (2 * sizeof(int64_t) + 2 * sizeof(int32_t));
     if ((rc = e->reserve(e->in_seqs, (size_t)seqs_bytes + 16, "hipMalloc(seqs)")) != TSTA_OK) return rc;
     if ((rc = e->reserve(e->in_meta, meta_bytes, "hipMalloc(meta)")) != TSTA_OK) return rc;
@@ -166,16 +183,17 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     int32_t* d_len2 = d_len1 + nb;
     hipStream_t s = e->stream;
     if ((rc = e->check(hipMemcpyAsync(e->in_seqs.p, seqs, (size_t)seqs_bytes, hipMemcpyHostToDevice, s), "H2D seqs")) ||
-        (rc = e->check(hipMemcpyAsync(d_off1, off1, nb * 8, hipMemcpyHostToDevice, s), "H2D off1")) ||
-        (rc = e->check(hipMemcpyAsync(d_off2, off2, nb * 8, hipMemcpyHostToDevice, s), "H2D off2")) ||
-        (rc = e->check(hipMemcpyAsync(d_len1, len1, nb * 4, hipMemcpyHostToDevice, s), "H2D len1")) ||
-        (rc = e->check(hipMemcpyAsync(d_len2, len2, nb * 4, hipMemcpyHostToDevice, s), "H2D len2")))
+        (rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
+        (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")))
         return rc;
     rc = tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                   d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
-    if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
-    return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
+    std::vector<int32_t> h_out(nb);
+    if ((rc = e->check(hipMemcpyAsync(h_out.data(), e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
+    if ((rc = e->check(hipStreamSynchronize(s), "psa_score_batch sync"))) return rc;
+    for (size_t k = 0; k < nb; ++k) out[perm[k]] = h_out[k];
+    return TSTA_OK;
 }
 
 }  // extern "C"
