@@ -203,6 +203,29 @@ def test_host_api_groups_equal_geometry(eng):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=10, X=-10, E=-3, O=-12)])
+def test_packed_couples_of_unequal_size(eng, scoring):
+    # pairs of different size may share a wave (the smaller is padded to the larger and masked): every combination of
+    # longer/shorter columns and rows, around the band / block boundaries, related and unrelated content
+    dims = [((1024, 1024), (1000, 900)), ((2048, 1030), (2047, 1024)), ((700, 64), (690, 65)), ((3000, 2900), (2800, 2950 - 200)),
+            ((129, 128), (128, 127)), ((5000, 4096), (4990, 4097 - 97)), ((64, 1), (63, 2)), ((2000, 2000), (1999, 1)),
+            ((4097, 1100), (4000, 1024))]
+    pairs = []
+    for i, ((n1, m1), (n2, m2)) in enumerate(dims):
+        for j, (n, m) in enumerate(((n1, m1), (n2, m2))):
+            a = util.random_dna(91_000 + 10 * i + j, n)
+            b = _fixed_len(util.mutate(a, 92_000 + 10 * i + j, 0.07), m, i) if (i + j) % 2 == 0 else util.random_dna(93_000 + 10 * i + j, m)
+            pairs.append((a, b) if (i % 3) else (b, a))
+    want = util.oracle_maxscore_batch(pairs, **scoring)
+    try:
+        for mode in (16, 8):
+            eng.set_option("psa_packed", mode)
+            got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+            assert np.array_equal(got, want), (mode, scoring, got.tolist(), want.tolist())
+    finally:
+        eng.set_option("psa_packed", -1)
+
+
 def test_set_option_rejects_unknown(eng):
     with pytest.raises(tsta_amd.TstaError):
         eng.set_option("no_such_knob", 1)

@@ -155,8 +155,9 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     const size_t nb = (size_t)n_pairs;
-    // Order the pairs by oriented geometry (columns n, rows m) so that equal-geometry pairs sit next to each other and
-    // can share a wave in the packed kernel (couples are adjacent pairs); results are scattered back to the caller's order.
+    // Order the pairs by oriented geometry (columns n, rows m) so that pairs of equal / similar size sit next to each
+    // other and can share a wave in the packed kernel (couples are adjacent pairs, the smaller one is padded to the
+    // larger); results are scattered back to the caller's order.
     std::vector<int64_t> perm(nb);
     for (size_t k = 0; k < nb; ++k) perm[k] = (int64_t)k;
     auto key = [&](int64_t k) {

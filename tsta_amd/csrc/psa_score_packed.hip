@@ -7,7 +7,8 @@
 //     can cross the halves because scores are kept biased and non-negative), and
 //   * v_pk_max_u16 / v_pk_min_u16 for the five max/min,
 // i.e. 6 fast + 6 packed ops per TWO cells.  The two halves of every register belong to two different pairs
-// (a "couple") with identical geometry; their lanes, skew, band hand-off and DPP traffic are shared.
+// (a "couple") of similar size; their lanes, skew, band hand-off and DPP traffic are shared.  Pairs of different
+// size are padded to the larger one (cells outside the smaller pair are masked out of its running max).
 //
 // Scores are stored as  v = H - base + 0x8000  with an int32 `base` per pair that is re-anchored to the band's
 // top row every 64 steps; all values live within (64R+192)*U of the base (U = per-step score bound), which the
@@ -52,7 +53,8 @@ struct PLane {
 // (E' = Ebar'(i-1,j) - |E|, same column) and the horizontal gap pays the shift:  F' = Fbar'(i,j-1) - (|E|+M).
 // That removes one add per cell; the price is one add + one max per STEP to feed the running max in the H frame.
 template <int R, bool PRED, bool PARTIAL>
-__device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nvalid,
+__device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
+                                      const int nvA, const int nvB,
                                       const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
                                       const unsigned pf)
 {
@@ -82,7 +84,7 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
         const unsigned fbn = pkmax(f, g);
         d = s.hl[k];
         unsigned hv = h;
-        if (PARTIAL) hv = (k < nvalid) ? hv : 0u;
+        if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);   // rows beyond m of either pair
         if (PRED) {
             s.hl[k] = act ? h : s.hl[k];
             s.fb[k] = act ? fbn : s.fb[k];
@@ -98,8 +100,11 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
     // running max in the H frame: H - anchor = H' + (column - anchor column)*M ; joff >= 0, no carry across halves
     unsigned cand = m + s.joff;
-    if (PRED) cand = act ? cand : 0u;
-    if (PARTIAL) cand = (nvalid > 0) ? cand : 0u;
+    if (PRED) {                                         // columns outside either pair's sequence do not count
+        const unsigned c = (unsigned)(t - lane);
+        cand &= ((c < (unsigned)nA) ? 0xffffu : 0u) | ((c < (unsigned)nB) ? 0xffff0000u : 0u);
+    }
+    if (PARTIAL) cand &= ((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u);
     s.mx = pkmax(s.mx, cand);
     s.joff += pm;
 }
@@ -120,9 +125,12 @@ __device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc)
 // 1.1 -> 2.0+ cycles), so the four packed constants are pinned in VGPRs.
 __device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "s"(x)); return x; }
 
+// The two pairs of a couple may differ in size: the wave sweeps max(nA,nB) columns and max(mA,mB) rows; cells
+// outside the smaller pair compute garbage that only feeds other such cells and is masked out of its running max.
 template <int R, bool PARTIAL>
-__device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int n,
-                                      const uint8_t* __restrict__ bA, const uint8_t* __restrict__ bB, const int m,
+__device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int nA, const int nB,
+                                      const uint8_t* __restrict__ bA, const uint8_t* __restrict__ bB, const int mA, const int mB,
+                                      const bool store_bottom,
                                       const int band_row0, int2* __restrict__ rowA, int2* __restrict__ rowB,
                                       PairAcc& acc, const int lane, const int M, const int E, const int O,
                                       const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s)
@@ -130,12 +138,13 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     const unsigned pe = in_vgpr(pe_s), po = in_vgpr(po_s), pm = in_vgpr(pm_s), pmx = in_vgpr(pmx_s);
     const unsigned pf = pe + pm;                   // |E| + M: the horizontal gap pays the column shift of the H' frame
     PLane<R> s;
+    const int n = max(nA, nB), nmin = min(nA, nB);
     const int i0 = band_row0 + lane * R;
-    const int nvalid = m - i0;
+    const int nvA = mA - i0, nvB = mB - i0;
     // anchor of the H' frame: the band's top row at the first column (H' = H - (column index + 1) * M)
     int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
     int naA = 0, naB = 0;
-    { const int l0 = opaque(lane); if (l0 < n) { ntA = rowA[l0]; ntB = rowB[l0]; naA = aA[l0]; naB = aB[l0]; } }
+    { const int l0 = opaque(lane); if (l0 < nA) { ntA = rowA[l0]; naA = aA[l0]; } if (l0 < nB) { ntB = rowB[l0]; naB = aB[l0]; } }
     acc.baseA = __builtin_amdgcn_readfirstlane(ntA.x) - M;
     acc.baseB = __builtin_amdgcn_readfirstlane(ntB.x) - M;
 #pragma unroll
@@ -143,8 +152,8 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         const int hk = hcol0p(i0 + 1 + k, E, O);   // column 0: H' = H
         s.hl[k] = pack2(hk - acc.baseA + kBias, hk - acc.baseB + kBias);
         s.fb[k] = pack2(hk + O - acc.baseA + kBias, hk + O - acc.baseB + kBias);
-        const int cA = (i0 + k < m) ? ((int)bA[i0 + k] << 8) : 0x1ff;
-        const int cB = (i0 + k < m) ? ((int)bB[i0 + k] << 8) : 0x1ff;
+        const int cA = (i0 + k < mA) ? ((int)bA[i0 + k] << 8) : 0x1ff;
+        const int cB = (i0 + k < mB) ? ((int)bB[i0 + k] << 8) : 0x1ff;
         s.bch[k] = pack2(cA, cB);
     }
     {
@@ -159,8 +168,9 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         if (t0 > 0 && t0 < n) {
             // re-anchor both pairs to the band's top row at column t0
             fold_max<R>(s, acc);
-            const int nbA = __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M;
-            const int nbB = __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M;
+            // (a pair whose columns are exhausted keeps its last anchor: its lanes hold garbage from here on)
+            const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
+            const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
             const unsigned pd = pack2(nbA - acc.baseA, nbB - acc.baseB);
             acc.baseA = nbA; acc.baseB = nbB;
 #pragma unroll
@@ -180,16 +190,17 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         }
         s.ach = pack2(naA << 8, naB << 8);
         const int cn = t0 + 64 + ln;
-        if (cn < n) { ntA = rowA[cn]; ntB = rowB[cn]; naA = aA[cn]; naB = aB[cn]; }
-        if (t0 >= 64 && t0 + 63 < n) {
+        if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
+        if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
+        if (t0 >= 64 && t0 + 63 < nmin) {
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx, pf);
+            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL>(s, t0 + q, lane, n, nvalid, pe, po, pm, pmx, pf);
+            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
         const int cs = t0 - 64 + opaque(lane);
-        if (!PARTIAL && cs >= 0 && cs < n) {
+        if (store_bottom && cs >= 0 && cs < n) {
             const int sh_m = (cs + 1) * M;
             rowA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
             rowB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
@@ -200,9 +211,11 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
 
 template <int R>
 __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
-                                              int n, int m, int2* rowA, int2* rowB, int lane, int M, int E, int O,
+                                              int nA, int mA, int nB, int mB, int2* rowA, int2* rowB, int lane,
+                                              int M, int E, int O,
                                               unsigned pe, unsigned po, unsigned pm, unsigned pmx, int& outA, int& outB)
 {
+    const int n = max(nA, nB), mmax = max(mA, mB), mmin = min(mA, mB);
     for (int c = opaque(lane); c < n; c += 64) {          // blockmatrix_init, psa.c:221-226
         const int h = O + (c + 1) * E;
         rowA[c] = make_int2(h, h + O);
@@ -211,12 +224,12 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     wave_mem_sync();
     PairAcc acc; acc.baseA = 0; acc.baseB = 0; acc.ancA = 0; acc.ancB = 0; acc.mxA = kNegInfP; acc.mxB = kNegInfP;
     constexpr int BAND = 64 * R;
-    int r0 = 0;
-    for (; r0 + BAND <= m; r0 += BAND) {
-        pband<R, false>(aA, aB, n, bA, bB, m, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
-        wave_mem_sync();
+    for (int r0 = 0; r0 < mmax; r0 += BAND) {
+        const bool last = r0 + BAND >= mmax;
+        if (r0 + BAND <= mmin) pband<R, false>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
+        else                   pband<R, true>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
+        if (!last) wave_mem_sync();
     }
-    if (r0 < m) pband<R, true>(aA, aB, n, bA, bB, m, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
     outA = wave_max(acc.mxA);
     outB = wave_max(acc.mxB);
 }
@@ -245,9 +258,10 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         const bool swa = l2a > l1a, swb = l2b > l1b;            // psa.c:194-199
         const uint8_t* aA = swa ? s2a : s1a; const uint8_t* bA = swa ? s1a : s2a;
         const uint8_t* aB = swb ? s2b : s1b; const uint8_t* bB = swb ? s1b : s2b;
-        const int n = swa ? l2a : l1a, m = swa ? l1a : l2a;
+        const int nA = swa ? l2a : l1a, mA = swa ? l1a : l2a;
+        const int nB = swb ? l2b : l1b, mB = swb ? l1b : l2b;
         int ra, rb;
-        pscore_couple<R>(aA, bA, aB, bB, n, m, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, ra, rb);
+        pscore_couple<R>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, ra, rb);
         if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
         wave_mem_sync();
     }
