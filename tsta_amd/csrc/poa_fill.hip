@@ -38,8 +38,10 @@ struct PoaArgs {
     int V, n;
     const int* pred_off; const int* pred; const uint8_t* base; const uint8_t* is_sink;
     const uint8_t* seq;                  // n bytes
-    int* Hrow;                           // [V+1][pitch]: Hrow[r][c+3] = H(r,c), c = 0..n   (row V = virtual init)
-    int* Erow;                           // [V+1][pitch]: Erow[r][c]   = Eagg(r,c+1), c = 0..n-1
+    const int* slot;                     // [V]: row slot of node r (slots are recycled once no later tile needs the row)
+    const int* pred_slot;                // parallel to pred[]: slot of that predecessor
+    int* Hrow;                           // [nslots][pitch]: Hrow[slot][c+3] = H(r,c), c = 0..n   (slot 0 = virtual init)
+    int* Erow;                           // [nslots][pitch]: Erow[slot][c]   = Eagg(r,c+1), c = 0..n-1
     int64_t pitch;                       // ints per row, multiple of 4
     int* carry;                          // [V][nchunks+1]: Fbar entering chunk q of row r
     uint8_t* cflag;                      // [V][nchunks+1]: "F at the first column of chunk q is an open"
@@ -56,7 +58,7 @@ __device__ __forceinline__ int dpp_shr1(int old, int src) { return __builtin_amd
 __global__ void poa_init_kernel(PoaArgs A)
 {
     // virtual init row (c-t-simd.c:82-94,174-188): H = 0, O+c*E ; no vertical gap state
-    int* Hi = A.Hrow + (size_t)A.V * A.pitch; int* Ei = A.Erow + (size_t)A.V * A.pitch;
+    int* Hi = A.Hrow; int* Ei = A.Erow;                       // slot 0
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= A.n; c += gridDim.x * blockDim.x) {
         Hi[c + 3] = c == 0 ? 0 : A.O + c * A.E;
         Ei[c] = kNeg;
@@ -83,18 +85,20 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
 
     // per-row side data of this tile, row r0+i in lane i
     int xin_l = 0, flag_l = 1, edge_l = 0;
+    int slot_l = 0;
+    if (r0 + lane < r1) slot_l = A.slot[r0 + lane];
     if (q > 0 && r0 + lane < r1) {
         xin_l = A.carry[(size_t)(r0 + lane) * ncar + q];
         flag_l = A.cflag[(size_t)(r0 + lane) * ncar + q];
-        edge_l = A.Hrow[(size_t)(r0 + lane) * A.pitch + cbase + 3];       // H(row, column cbase) from tile q-1
+        edge_l = A.Hrow[(size_t)slot_l * A.pitch + cbase + 3];            // H(row, column cbase) from tile q-1
     }
     // DAG metadata of the tile's rows, one row per lane (avoids dependent scalar loads on the per-row critical path)
-    int poff_l = 0, np_l = 0, base_l = 0, pfirst_l = -1;
+    int poff_l = 0, np_l = 0, base_l = 0, pfirst_l = -1, pfslot_l = 0;
     if (r0 + lane < r1) {
         poff_l = A.pred_off[r0 + lane];
         np_l = A.pred_off[r0 + lane + 1] - poff_l;
         base_l = A.base[r0 + lane];
-        if (np_l > 0) pfirst_l = A.pred[poff_l];
+        if (np_l > 0) { pfirst_l = A.pred[poff_l]; pfslot_l = A.pred_slot[poff_l]; }
     }
     // scan weights: distance (in lanes) to the source lane of the two cross-row DPP broadcasts
     const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
@@ -107,10 +111,11 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
     for (int r = r0; r < r1; ++r) {
         const int i = r - r0;
         const int p0 = __builtin_amdgcn_readlane(poff_l, i), np = __builtin_amdgcn_readlane(np_l, i);
-        const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i);
+        const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i), pfslot = __builtin_amdgcn_readlane(pfslot_l, i);
         const bool is_src = (np == 0);                       // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
-        int* Hr = A.Hrow + (size_t)r * A.pitch;
-        int* Er = A.Erow + (size_t)r * A.pitch;
+        const int myslot = __builtin_amdgcn_readlane(slot_l, i);
+        int* Hr = A.Hrow + (size_t)myslot * A.pitch;
+        int* Er = A.Erow + (size_t)myslot * A.pitch;
         const int bs = __builtin_amdgcn_readlane(base_l, i);
         // first column (c-t-simd.c:187,194-200) - chunk 0 only
         int h0 = 0, xin_row, flag_row;
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                 h0 = kNeg;
                 for (int j = 0; j < np; ++j) {
                     const int p = (j == 0) ? pfirst : A.pred[p0 + j];
-                    h0 = max(h0, (p == prev_r) ? h0_prev : A.Hrow[(size_t)p * A.pitch + 3]);
+                    const int ps = (j == 0) ? pfslot : A.pred_slot[p0 + j];
+                    h0 = max(h0, (p == prev_r) ? h0_prev : A.Hrow[(size_t)ps * A.pitch + 3]);
                 }
                 h0 += E;
             }
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
         bool synced = false;
         for (int j = 0; j < npp; ++j) {
             const int p = is_src ? A.V : ((j == 0) ? pfirst : A.pred[p0 + j]);
+            const int ps = is_src ? 0 : ((j == 0) ? pfslot : A.pred_slot[p0 + j]);
             int hv[KC + 1], ev[KC];
             if (p == prev_r) {
                 // predecessor = the row this wave has just finished: registers + one lane shift, no memory
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     synced = true;
                 }
-                const int* Hp = A.Hrow + (size_t)p * A.pitch + c0 + 3;     // H(p, c0 .. c0+KC)
-                const int* Ep = A.Erow + (size_t)p * A.pitch + c0;         // Eagg(p, c0+1 .. c0+KC)
+                const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+KC)
+                const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+KC)
                 hv[0] = Hp[0];
                 if constexpr (KC == 4) {
                     const int4 ha = *reinterpret_cast<const int4*>(Hp + 1);
@@ -321,8 +328,33 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     const int nchunks = (n + cw - 1) / cw, nrb = (V + tsta::kRB - 1) / tsta::kRB;
     const int64_t pitch = ((int64_t)nchunks * cw + 8 + 3) / 4 * 4 + 8;
     const int64_t tpitch = ((int64_t)nchunks * cw + 7) / 8 * 8;
-    const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 4 + (size_t)V * 2 + (size_t)n + 64;
-    const size_t rows_bytes = (size_t)(V + 1) * pitch * sizeof(int);
+    // Row slots: a node's H/Eagg row is needed until its last successor's tiles have run.  Tiles are launched by
+    // anti-diagonal (chunk q + row-block rb), so a slot freed by a node whose last reader sits in row-block rbL may be
+    // rewritten only by rows of row-blocks >= rbL + 2 (a kernel boundary then separates every old read from the new
+    // write, including the left-edge column that belongs to the chunk on the left).  Slot 0 is the virtual init row.
+    std::vector<int> slot(V), pslot(std::max(npred, 1));
+    int nslots = 1;
+    {
+        std::vector<int> last_use(V);
+        for (int r = 0; r < V; ++r) last_use[r] = r;
+        for (int r = 0; r < V; ++r)
+            for (int k = dag->pred_off[r]; k < dag->pred_off[r + 1]; ++k) last_use[dag->pred[k]] = std::max(last_use[dag->pred[k]], r);
+        std::vector<std::pair<int, int>> heap;                 // (release row-block, slot), min-heap
+        auto cmp = [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; };
+        for (int r = 0; r < V; ++r) {
+            const int rb = r / tsta::kRB;
+            if (!heap.empty() && heap.front().first <= rb) {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                slot[r] = heap.back().second;
+                heap.pop_back();
+            } else slot[r] = nslots++;
+            heap.emplace_back(last_use[r] / tsta::kRB + 2, slot[r]);
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        for (int k = 0; k < npred; ++k) pslot[k] = slot[dag->pred[k]];
+    }
+    const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 8 + (size_t)V * 4 + (size_t)V * 2 + (size_t)n + 64;
+    const size_t rows_bytes = (size_t)nslots * pitch * sizeof(int);
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)")) ||
         (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)")) ||
         (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)")) ||
@@ -334,11 +366,15 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     char* m = reinterpret_cast<char*>(e->in_meta.p);
     int* d_off = reinterpret_cast<int*>(m);
     int* d_pred = d_off + (V + 1);
-    uint8_t* d_base = reinterpret_cast<uint8_t*>(d_pred + std::max(npred, 1));
+    int* d_pslot = d_pred + std::max(npred, 1);
+    int* d_slot = d_pslot + std::max(npred, 1);
+    uint8_t* d_base = reinterpret_cast<uint8_t*>(d_slot + V);
     uint8_t* d_sink = d_base + V;
     uint8_t* d_seq = d_sink + V;
     if ((rc = e->check(hipMemcpyAsync(d_off, dag->pred_off, (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s), "H2D pred_off")) ||
         (npred && (rc = e->check(hipMemcpyAsync(d_pred, dag->pred, (size_t)npred * 4, hipMemcpyHostToDevice, s), "H2D pred"))) ||
+        (npred && (rc = e->check(hipMemcpyAsync(d_pslot, pslot.data(), (size_t)npred * 4, hipMemcpyHostToDevice, s), "H2D pred slots"))) ||
+        (rc = e->check(hipMemcpyAsync(d_slot, slot.data(), (size_t)V * 4, hipMemcpyHostToDevice, s), "H2D slots")) ||
         (rc = e->check(hipMemcpyAsync(d_base, dag->base, V, hipMemcpyHostToDevice, s), "H2D base")) ||
         (rc = e->check(hipMemcpyAsync(d_sink, dag->is_sink, V, hipMemcpyHostToDevice, s), "H2D is_sink")) ||
         (rc = e->check(hipMemcpyAsync(d_seq, seq, n, hipMemcpyHostToDevice, s), "H2D seq")))
@@ -346,8 +382,9 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
 
     PoaArgs A;
     A.V = V; A.n = n; A.pred_off = d_off; A.pred = d_pred; A.base = d_base; A.is_sink = d_sink; A.seq = d_seq;
+    A.slot = d_slot; A.pred_slot = d_pslot;
     A.Hrow = reinterpret_cast<int*>(e->rows.p);
-    A.Erow = A.Hrow + (size_t)(V + 1) * pitch;
+    A.Erow = A.Hrow + (size_t)nslots * pitch;
     A.pitch = pitch;
     A.tpitch = tpitch;
     A.carry = reinterpret_cast<int*>(e->scratch.p);
