@@ -113,6 +113,23 @@ int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* da
                   int32_t* best_sink);
 
 /* ------------------------------------------------------------------------------------------------
+ * POA fill + traceback walk  ==  control() up to and including the WALK of node_fuse (c-t-simd.c:737-957), i.e.
+ * everything of node_fuse that reads the trace arrays; the graph surgery itself stays with the caller.  The
+ * 3 x n_nodes x n trace bytes never leave HBM.  One step per visited cell, in visiting order (from the best sink
+ * and the last character backwards):
+ *   node  sort index of the graph node,  col  0-based sequence position,
+ *   code  the EFFECTIVE source code of the cell (after the forced-continuation overwrites, :767-769, :776-782):
+ *         code/42 = 3 F (insert the character), 0 E (skip the node), 1 match, 2 mismatch; code%42 = predecessor index
+ *   peek  for match/mismatch cells: 1 iff the diagonal predecessor cell is itself a match (:790, :827, :873)
+ * end_col = sequence position at which the walk stopped (-1: sequence consumed; >= 0: that prefix becomes new nodes,
+ * :959-972).  steps is malloc'd: free with tsta_free().  lastscore may be NULL.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct tsta_poa_step { int32_t node, col; int8_t code, peek; int16_t pad; } tsta_poa_step;
+
+int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
+                   int32_t n, tsta_poa_step** steps, int64_t* n_steps, int32_t* end_col, int32_t* lastscore);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): duration of the kernels of the last *_dev / host call, measured with HIP
  * events on the stream they ran on, and the number of kernel launches it took.
  * ------------------------------------------------------------------------------------------------ */

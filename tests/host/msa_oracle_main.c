@@ -20,5 +20,5 @@ int main(int argc, char** argv)
 {
     if (argc < 7) return 2;
     oracle_params p = { atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) };
-    return msa_run(argv[5], argv[6], oracle_fill, &p);
+    return msa_run(argv[5], argv[6], oracle_fill, NULL, &p);
 }

@@ -95,3 +95,27 @@ def test_rejects_bad_dags(eng):
     with pytest.raises(tsta_amd.TstaError):
         eng.poa_fill(np.array(pred_off, np.int32), np.arange(43, dtype=np.int32), util.random_dna(2, V),
                      np.ones(V, np.uint8), seq)
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[4:-4] for p in FIXTURES])
+def test_on_device_walk_matches_host_walk(eng, path):
+    # tsta_poa_align (fill + walk on the GPU) vs the same walk done in Python over the arrays tsta_poa_fill returns
+    z, sc = load(path)
+    args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+    best, last, src, es, fs = eng.poa_fill(*args, tsta_amd.Params(**sc))
+    want, want_end = util.poa_walk(z["pred_off"], z["pred"], z["is_sink"], last, src, es, fs)
+    steps, end_col, last2 = eng.poa_align(*args, tsta_amd.Params(**sc))
+    assert np.array_equal(last, last2)
+    assert end_col == want_end
+    got = [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps]
+    assert got == want
+
+
+def test_on_device_walk_random_dags(eng):
+    for seed, V, mp, n in [(11, 300, 6, 257), (12, 2000, 3, 100), (13, 90, 20, 1500)]:
+        pred_off, pred, base, is_sink, seq = random_dag(seed, V, mp, n)
+        best, last, src, es, fs = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+        want, want_end = util.poa_walk(pred_off, pred, is_sink, last, src, es, fs)
+        steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
+        got = [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps]
+        assert (got, end_col) == (want, want_end)

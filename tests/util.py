@@ -223,3 +223,38 @@ def cpu_has(flag):
             return flag in f.read()
     except OSError:
         return False
+
+
+def poa_walk(pred_off, pred, is_sink, lastscore, src, es, fs):
+    """Python restatement of the trace walk of node_fuse (c-t-simd.c:737-957) over full [V][n] arrays.
+    -> (list of (node, col, code, peek), end_col).  Test infrastructure (mirrors walk_arrays in poa_graph.c)."""
+    V, n = src.shape
+    sinks = [i for i in range(1, V) if is_sink[i]]
+    num1 = V - 1
+    if sinks:
+        best = max(lastscore[i] for i in sinks)
+        num1 = min(i for i in sinks if lastscore[i] == best)
+    num2, forced, steps = n - 1, -1, []
+    while num1 != -1 and num2 != -1:
+        code = forced if forced >= 0 else int(src[num1, num2])
+        forced = -1
+        kind, pidx = code // 42, code % 42
+        npred = pred_off[num1 + 1] - pred_off[num1]
+        psub = int(pred[pred_off[num1] + pidx]) if pidx < npred else -1
+        peek = 0
+        if kind == 3:
+            f = int(fs[num1, num2])
+            if num2 - 1 > 0 and (abs(f) == 1 or (abs(f) == 2 and fs[num1, num2 - 1] < 0)):
+                forced = 126
+            steps.append((num1, num2, code, 0)); num2 -= 1
+        elif kind == 0:
+            e = int(es[num1, num2])
+            if psub > 0 and (-42 <= e <= 42 or ((e > 42 or e < -42) and es[psub, num2] < 0)):
+                v = int(es[psub, num2]); r = abs(v) % 42          # C remainder: sign follows the dividend
+                forced = r - 1
+            steps.append((num1, num2, code, 0)); num1 = psub
+        else:
+            if psub >= 0 and num2 - 1 >= 0:
+                peek = 1 if int(src[psub, num2 - 1]) // 42 == 1 else 0
+            steps.append((num1, num2, code, peek)); num1 = psub; num2 -= 1
+    return steps, num2

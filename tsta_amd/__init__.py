@@ -18,7 +18,7 @@ lib_path = os.path.join(_HERE, "lib", "libtsta_hip.so")
 EXPORTED_SYMBOLS = [
     "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
-    "tsta_last_kernel_ms", "tsta_engine_set_option",
+    "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align",
 ]
 
 
@@ -77,6 +77,9 @@ def lib():
                                      C.POINTER(vp), C.POINTER(i64)]
         L.tsta_poa_fill.restype = C.c_int
         L.tsta_poa_fill.argtypes = [vp, C.POINTER(Params), C.POINTER(DagCsr), vp, i32, vp, vp, vp, vp, C.POINTER(i32)]
+        L.tsta_poa_align.restype = C.c_int
+        L.tsta_poa_align.argtypes = [vp, C.POINTER(Params), C.POINTER(DagCsr), vp, i32, C.POINTER(vp), C.POINTER(i64),
+                                     C.POINTER(i32), vp]
         L.tsta_last_kernel_ms.restype = C.c_int
         L.tsta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
         _lib = L
@@ -192,6 +195,27 @@ class Engine:
                                  _ptr(fs) if want_trace else None, _ptr(last), C.byref(best))
         self._check(rc, "tsta_poa_fill")
         return int(best.value), last, src, es, fs
+
+    def poa_align(self, pred_off, pred, base, is_sink, seq, params=None):
+        """Fill + on-device traceback walk.  -> (steps, end_col, lastscore); steps is a structured array with fields
+        node, col, code, peek (tsta_poa_step)."""
+        params = params or Params()
+        pred_off = np.ascontiguousarray(pred_off, dtype=np.int32)
+        pred = np.ascontiguousarray(pred if len(pred) else np.zeros(1), dtype=np.int32)
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        is_sink = np.ascontiguousarray(is_sink, dtype=np.uint8)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        V, n = len(base), len(seq)
+        dag = DagCsr(V, _ptr(pred_off).value, _ptr(pred).value, _ptr(base).value, _ptr(is_sink).value)
+        last = np.zeros(V, dtype=np.int32)
+        st, ns, ec = C.c_void_p(), C.c_int64(), C.c_int32()
+        rc = lib().tsta_poa_align(self._h, C.byref(params), C.byref(dag), _ptr(seq), n, C.byref(st), C.byref(ns),
+                                  C.byref(ec), _ptr(last))
+        self._check(rc, "tsta_poa_align")
+        dt = np.dtype([("node", np.int32), ("col", np.int32), ("code", np.int8), ("peek", np.int8), ("pad", np.int16)])
+        steps = np.frombuffer(C.string_at(st, ns.value * dt.itemsize), dtype=dt).copy() if ns.value else np.zeros(0, dt)
+        lib().tsta_free(st)
+        return steps, int(ec.value), last
 
     def last_kernel_ms(self):
         ms, nl = C.c_float(), C.c_int32()

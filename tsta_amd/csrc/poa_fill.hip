@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <climits>
 #include <vector>
 
 #include "../../include/tsta_engine.h"
@@ -295,21 +296,117 @@ __global__ void poa_best_kernel(PoaArgs A)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- K4w
+// The traceback walk of node_fuse (c-t-simd.c:737-957) next to the trace arrays, so that the 3 x V x n bytes never
+// leave HBM: one wave stages a 64-node x 64-column window of source/esource/fsource in LDS, every lane follows the
+// walk redundantly (wave-uniform control flow), lane 0 records one step per visited cell.  Cells outside the window
+// (far predecessors) are read from HBM.  Output: tsta_poa_step[] = {node, col, effective code, peek}.
+struct PoaWalkArgs {
+    int V, n;
+    const int* pred_off; const int* pred; const uint8_t* is_sink;
+    const int8_t* source; const int8_t* esource; const int8_t* fsource; int64_t tpitch;
+    const int* lastscore;
+    tsta_poa_step* steps;                // out, capacity V + n + 2
+    int* out;                            // out[0] = number of steps, out[1] = end column, out[2] = start node
+};
+
+__global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
+{
+    __shared__ uint4 win[3][64][4];      // [array][row][64 bytes]
+    const int lane = threadIdx.x;
+    // start: best sink among sort indices >= 1 (max lastsorce, lowest index on ties), else the last node (:737-750)
+    int bv = INT_MIN, bi = -1;
+    for (int i = 1 + lane; i < A.V; i += 64)
+        if (A.is_sink[i] && (bi < 0 || A.lastscore[i] > bv)) { bv = A.lastscore[i]; bi = i; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    int num1 = __builtin_amdgcn_readfirstlane(bi >= 0 ? bi : A.V - 1);
+    int num2 = A.n - 1, forced = -1, ns = 0;
+    if (lane == 0) A.out[2] = num1;
+
+    while (num1 != -1 && num2 != -1) {
+        // stage the window whose lower-right region holds (num1, num2)
+        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
+        {
+            const int rr = rw0 + lane;
+            uint4 t[3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int64_t col = cw0 + 16 * x;
+                    t[a][x] = (rr < A.V && col < A.tpitch) ? *reinterpret_cast<const uint4*>(base + (size_t)rr * A.tpitch + col)
+                                                            : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) win[a][lane][x] = t[a][x];
+        }
+        __syncthreads();
+        const int8_t* wb = reinterpret_cast<const int8_t*>(win);
+        auto rd = [&](int a, int row, int col) -> int {      // trace byte of array a at (row, col)
+            if (row >= rw0 && row < rw0 + 64 && col >= cw0 && col < cw0 + 64)
+                return wb[(a * 64 + (row - rw0)) * 64 + (col - cw0)];
+            const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
+            return base[(size_t)row * A.tpitch + col];
+        };
+        for (;;) {
+            if (num1 == -1 || num2 == -1) break;
+            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + 64) break;        // restage
+            int code;
+            if (forced >= 0) { code = forced; forced = -1; } else code = __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
+            const int kind = code / 42, pidx = code % 42;
+            const int p0 = A.pred_off[num1], np = A.pred_off[num1 + 1] - p0;
+            const int Psub = (pidx < np) ? A.pred[p0 + pidx] : -1;
+            int peek = 0;
+            int n1 = num1, n2 = num2;
+            if (kind == 3) {                                   // F (:753-772)
+                const int fs = __builtin_amdgcn_readfirstlane(rd(2, num1, num2));
+                const int afs = fs < 0 ? -fs : fs;
+                if (num2 - 1 > 0 && (afs == 1 || (afs == 2 && __builtin_amdgcn_readfirstlane(rd(2, num1, num2 - 1)) < 0))) forced = 126;
+                n2 = num2 - 1;
+            } else if (kind == 0) {                            // E (:773-785)
+                const int es = __builtin_amdgcn_readfirstlane(rd(1, num1, num2));
+                if (Psub > 0) {
+                    const int esp = __builtin_amdgcn_readfirstlane(rd(1, Psub, num2));
+                    if ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && esp < 0)) {
+                        const int s5 = esp % 42;
+                        forced = (s5 < 0 ? -s5 : s5) - 1;
+                    }
+                }
+                n1 = Psub;
+            } else {                                           // match / mismatch (:786-860, :861-956)
+                if (Psub >= 0 && num2 - 1 >= 0) peek = (__builtin_amdgcn_readfirstlane(rd(0, Psub, num2 - 1)) / 42 == 1);
+                n1 = Psub; n2 = num2 - 1;
+            }
+            if (lane == 0) {
+                tsta_poa_step st; st.node = num1; st.col = num2; st.code = (int8_t)code; st.peek = (int8_t)peek; st.pad = 0;
+                A.steps[ns] = st;
+            }
+            ++ns;
+            num1 = n1; num2 = n2;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; }
+}
+
 }  // namespace tsta
 
-extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
-                             int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
-                             int32_t* best_sink)
+namespace tsta {
+
+// Validation, uploads, workspace and the fill launches; leaves everything on the device.
+static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
+                             bool want_trace, PoaArgs& A)
 {
-    using namespace tsta;
-    if (!eng || !p || !dag || n < 0 || dag->n_nodes < 0) return TSTA_ERR_INVALID_ARG;
-    Engine* e = reinterpret_cast<Engine*>(eng);
     const int V = dag->n_nodes;
-    if (best_sink) *best_sink = -1;
-    if (V == 0 || n == 0) return TSTA_OK;
-    if (!dag->pred_off || !dag->base || !dag->is_sink || !seq) return TSTA_ERR_INVALID_ARG;
-    const bool want_trace = source || esource || fsource;
-    if (want_trace && !(source && esource && fsource)) return TSTA_ERR_INVALID_ARG;
     const int npred = dag->pred_off[V];
     for (int r = 0; r < V; ++r) {
         const int k0 = dag->pred_off[r], k1 = dag->pred_off[r + 1];
@@ -325,9 +422,9 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     // which wins while the sequence is short enough that the tile wavefront is the limit
     const int kc = (e->opt_poa_cols == 2 || e->opt_poa_cols == 4) ? e->opt_poa_cols : (n <= 16384 ? 2 : 4);
     const int cw = 64 * kc;
-    const int nchunks = (n + cw - 1) / cw, nrb = (V + tsta::kRB - 1) / tsta::kRB;
+    const int nchunks = (n + cw - 1) / cw, nrb = (V + kRB - 1) / kRB;
     const int64_t pitch = ((int64_t)nchunks * cw + 8 + 3) / 4 * 4 + 8;
-    const int64_t tpitch = ((int64_t)nchunks * cw + 7) / 8 * 8;
+    const int64_t tpitch = ((int64_t)nchunks * cw + 15) / 16 * 16;
     // Row slots: a node's H/Eagg row is needed until its last successor's tiles have run.  Tiles are launched by
     // anti-diagonal (chunk q + row-block rb), so a slot freed by a node whose last reader sits in row-block rbL may be
     // rewritten only by rows of row-blocks >= rbL + 2 (a kernel boundary then separates every old read from the new
@@ -342,13 +439,13 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
         std::vector<std::pair<int, int>> heap;                 // (release row-block, slot), min-heap
         auto cmp = [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; };
         for (int r = 0; r < V; ++r) {
-            const int rb = r / tsta::kRB;
+            const int rb = r / kRB;
             if (!heap.empty() && heap.front().first <= rb) {
                 std::pop_heap(heap.begin(), heap.end(), cmp);
                 slot[r] = heap.back().second;
                 heap.pop_back();
             } else slot[r] = nslots++;
-            heap.emplace_back(last_use[r] / tsta::kRB + 2, slot[r]);
+            heap.emplace_back(last_use[r] / kRB + 2, slot[r]);
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
         for (int k = 0; k < npred; ++k) pslot[k] = slot[dag->pred[k]];
@@ -361,7 +458,7 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
         (rc = e->reserve(e->scratch, (size_t)V * (nchunks + 1) * 4 + 64, "hipMalloc(poa carry)")) ||
         (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)")))
         return rc;
-    if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch, "hipMalloc(poa trace)"))) return rc;
+    if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)"))) return rc;
 
     char* m = reinterpret_cast<char*>(e->in_meta.p);
     int* d_off = reinterpret_cast<int*>(m);
@@ -379,8 +476,9 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
         (rc = e->check(hipMemcpyAsync(d_sink, dag->is_sink, V, hipMemcpyHostToDevice, s), "H2D is_sink")) ||
         (rc = e->check(hipMemcpyAsync(d_seq, seq, n, hipMemcpyHostToDevice, s), "H2D seq")))
         return rc;
+    // the host vectors above must outlive the async copies
+    if ((rc = e->check(hipStreamSynchronize(s), "poa upload sync"))) return rc;
 
-    PoaArgs A;
     A.V = V; A.n = n; A.pred_off = d_off; A.pred = d_pred; A.base = d_base; A.is_sink = d_sink; A.seq = d_seq;
     A.slot = d_slot; A.pred_slot = d_pslot;
     A.Hrow = reinterpret_cast<int*>(e->rows.p);
@@ -409,19 +507,79 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     }
     hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
     e->n_launches = launches + 1;
-    e->timing_end(s);
-    if ((rc = e->check(hipGetLastError(), "poa_fill launch"))) return rc;
+    return e->check(hipGetLastError(), "poa_fill launch");
+}
 
+}  // namespace tsta
+
+extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
+                             int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
+                             int32_t* best_sink)
+{
+    using namespace tsta;
+    if (!eng || !p || !dag || n < 0 || dag->n_nodes < 0) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    const int V = dag->n_nodes;
+    if (best_sink) *best_sink = -1;
+    if (V == 0 || n == 0) return TSTA_OK;
+    if (!dag->pred_off || !dag->base || !dag->is_sink || !seq) return TSTA_ERR_INVALID_ARG;
+    const bool want_trace = source || esource || fsource;
+    if (want_trace && !(source && esource && fsource)) return TSTA_ERR_INVALID_ARG;
+    PoaArgs A;
+    int rc = poa_run_on_device(e, p, dag, seq, n, want_trace, A);
+    if (rc != TSTA_OK) return rc;
+    hipStream_t s = e->stream;
+    e->timing_end(s);
     int h_best = -1;
     if ((rc = e->check(hipMemcpyAsync(&h_best, A.best, 4, hipMemcpyDeviceToHost, s), "D2H best"))) return rc;
     if (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) return rc;
     if (want_trace) {
-        if ((rc = e->check(hipMemcpy2DAsync(source, n, A.source, tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
-            (rc = e->check(hipMemcpy2DAsync(esource, n, A.esource, tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
-            (rc = e->check(hipMemcpy2DAsync(fsource, n, A.fsource, tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
+        if ((rc = e->check(hipMemcpy2DAsync(source, n, A.source, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
+            (rc = e->check(hipMemcpy2DAsync(esource, n, A.esource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
+            (rc = e->check(hipMemcpy2DAsync(fsource, n, A.fsource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
             return rc;
     }
     if ((rc = e->check(hipStreamSynchronize(s), "poa_fill sync"))) return rc;
     if (best_sink) *best_sink = h_best;
+    return TSTA_OK;
+}
+
+extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
+                              int32_t n, tsta_poa_step** steps, int64_t* n_steps, int32_t* end_col, int32_t* lastscore)
+{
+    using namespace tsta;
+    if (!eng || !p || !dag || n < 0 || dag->n_nodes < 0 || !steps || !n_steps || !end_col) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    const int V = dag->n_nodes;
+    *steps = nullptr; *n_steps = 0; *end_col = n - 1;
+    if (V == 0 || n == 0) return TSTA_OK;
+    if (!dag->pred_off || !dag->base || !dag->is_sink || !seq) return TSTA_ERR_INVALID_ARG;
+    PoaArgs A;
+    int rc = poa_run_on_device(e, p, dag, seq, n, true, A);
+    if (rc != TSTA_OK) return rc;
+    hipStream_t s = e->stream;
+    const size_t cap = (size_t)V + (size_t)n + 2;
+    if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)"))) return rc;
+    PoaWalkArgs Wk;
+    Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink;
+    Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch;
+    Wk.lastscore = A.lastscore;
+    Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
+    Wk.out = A.best + 4;
+    hipLaunchKernelGGL(poa_walk_kernel, dim3(1), dim3(64), 0, s, Wk);
+    e->n_launches += 1;
+    e->timing_end(s);
+    if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
+    int h_out[4] = {0, 0, 0, 0};
+    if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
+        (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
+        (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
+        return rc;
+    const int ns = h_out[0];
+    if (ns < 0 || (size_t)ns > cap) { e->set_error("walker returned %d steps", ns); return TSTA_ERR_INTERNAL; }
+    tsta_poa_step* out = (tsta_poa_step*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(tsta_poa_step));
+    if (!out) return TSTA_ERR_OOM;
+    if (ns && (rc = e->check(hipMemcpy(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost), "D2H steps"))) { free(out); return rc; }
+    *steps = out; *n_steps = ns; *end_col = h_out[1];
     return TSTA_OK;
 }

@@ -35,6 +35,23 @@ static int gpu_fill(void* vctx, int n_nodes, const int32_t* pred_off, const int3
     return rc;
 }
 
+/* fill + traceback walk on the GPU: only the visited cells come back (tsta_poa_step == pg_step) */
+static void free_gpu_steps(void* p) { tsta_free(p); }
+
+static int gpu_path(void* vctx, int n_nodes, const int32_t* pred_off, const int32_t* pred, const uint8_t* base,
+                    const uint8_t* is_sink, const uint8_t* seq, int32_t n, pg_step** steps, int64_t* n_steps,
+                    int32_t* end_col, void (**free_steps)(void*))
+{
+    gpu_ctx* c = (gpu_ctx*)vctx;
+    tsta_dag_csr dag = { n_nodes, pred_off, pred, base, is_sink };
+    tsta_poa_step* st = NULL;
+    int rc = tsta_poa_align(c->eng, &c->prm, &dag, seq, n, &st, n_steps, end_col, NULL);
+    if (rc != TSTA_OK) fprintf(stderr, "tsta_poa_align: %s: %s\n", tsta_strerror(rc), tsta_last_error(c->eng));
+    *steps = (pg_step*)st;
+    *free_steps = free_gpu_steps;
+    return rc;
+}
+
 int main(int argc, char* argv[])
 {
     gpu_ctx ctx = { NULL, { 2, -5, -2, -4 } };
@@ -61,7 +78,11 @@ int main(int argc, char* argv[])
     const char* dev = getenv("TSTA_DEVICE");
     int rc = tsta_engine_create(dev ? atoi(dev) : 0, &ctx.eng);
     if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
-    rc = msa_run(input, output, gpu_fill, &ctx);
+    /* default: the walk runs on the GPU next to the trace arrays; TSTA_MSA_HOST_WALK=1 copies the arrays back instead */
+    if (getenv("TSTA_MSA_HOST_WALK")) rc = msa_run(input, output, gpu_fill, NULL, &ctx);
+    else                              rc = msa_run(input, output, NULL, gpu_path, &ctx);
     tsta_engine_destroy(ctx.eng);
     return rc ? 1 : 0;
 }
+
+_Static_assert(sizeof(pg_step) == sizeof(tsta_poa_step), "pg_step and tsta_poa_step must have the same layout");

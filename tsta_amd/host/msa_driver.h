@@ -5,5 +5,7 @@
 /* Reads every FASTA record of `input`, builds the POA progressively and writes the result file.
  * stderr "seq_num: %d\n" (msa.c:47), stdout progress "\r[i/N]" every 100 sequences, "\r[N/N]\n" (msa.c:135-139).
  * Returns 0, or the fill's error code. */
-int msa_run(const char* input, const char* output, pg_fill_fn fill, void* ctx);
+/* Exactly one of `fill` (returns the full trace arrays; the host walks them) and `path` (the walk was done next to
+ * the arrays, e.g. on the GPU) is non-NULL. */
+int msa_run(const char* input, const char* output, pg_fill_fn fill, pg_path_fn path, void* ctx);
 #endif

@@ -99,14 +99,73 @@ static void become_member(pg_graph* g, int id, int num, int slot, int set_sub)
 
 static int iabs(int v) { return v < 0 ? -v : v; }
 
-static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source, const int8_t* esource,
-                      const int8_t* fsource, const int32_t* lastscore)
+/* The trace walk of node_fuse, separated from the graph surgery: visits cells from (best sink, last character)
+ * following the trace codes and the forced-continuation rules, and records one pg_step per visited cell.
+ * This host version reads full [V][n] trace arrays (used with a fill that returns them, e.g. the test oracle);
+ * the GPU runs the same walk next to the arrays (poa_walk_kernel) so that they never leave HBM. */
+static pg_step* walk_arrays(const pg_graph* g, int len_b, const int32_t* pred_off, const int32_t* pred,
+                            const int8_t* source, const int8_t* esource, const int8_t* fsource,
+                            const int32_t* lastscore, int64_t* n_steps, int32_t* end_col)
 {
-    const int len_b = (int)strlen(b);
     const size_t W = (size_t)len_b;
 #define SRC(row, col) source[(size_t)(row) * W + (size_t)(col)]
 #define ESRC(row, col) esource[(size_t)(row) * W + (size_t)(col)]
 #define FSRC(row, col) fsource[(size_t)(row) * W + (size_t)(col)]
+    pg_step* steps = (pg_step*)malloc(((size_t)g->len + (size_t)len_b + 2) * sizeof(pg_step));
+    int64_t ns = 0;
+    int num1 = g->len - 1, num2 = len_b - 1, forced = -1;
+    /* start at the best sink: max lastsorce, the lowest sort index wins ties, index 0 is never looked at
+     * (c-t-simd.c:737-750) */
+    {
+        int s1 = INT_MIN, seen = 0;
+        for (int i = g->len - 1; i > 0; i--) {
+            const pg_node* nd = &g->nodes[g->sort[i]];
+            if (nd->out == 0) {
+                if (s1 <= lastscore[i]) { s1 = lastscore[i]; num1 = nd->sub; }
+                seen++;
+            }
+            if (seen >= g->last_node_num) break;
+        }
+    }
+    while (num1 != -1 && num2 != -1) {
+        int code;
+        if (forced >= 0) { code = forced; forced = -1; } else code = SRC(num1, num2);
+        const int kind = code / 42, pidx = code % 42;
+        const int np = pred_off[num1 + 1] - pred_off[num1];
+        const int Psub = (pidx < np) ? pred[pred_off[num1] + pidx] : -1;
+        pg_step st; st.node = num1; st.col = num2; st.code = (int8_t)code; st.peek = 0; st.pad = 0;
+        if (kind == 3) {                                   /* F (:753-772) */
+            const int fs = FSRC(num1, num2);
+            if (num2 - 1 > 0 && (iabs(fs) == 1 || (iabs(fs) == 2 && FSRC(num1, num2 - 1) < 0))) forced = 126;
+            steps[ns++] = st;
+            num2--;
+        } else if (kind == 0) {                            /* E (:773-785) */
+            const int es = ESRC(num1, num2);
+            if (Psub > 0 && ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && ESRC(Psub, num2) < 0))) {
+                int s5 = ESRC(Psub, num2) % 42;
+                forced = iabs(s5) - 1;
+            }
+            steps[ns++] = st;
+            num1 = Psub;
+        } else {                                           /* match / mismatch (:786-860, :861-956) */
+            st.peek = (int8_t)(Psub >= 0 && num2 - 1 >= 0 && SRC(Psub, num2 - 1) / 42 == 1);
+            steps[ns++] = st;
+            num1 = Psub;
+            num2--;
+        }
+    }
+#undef SRC
+#undef ESRC
+#undef FSRC
+    *n_steps = ns;
+    *end_col = num2;
+    return steps;
+}
+
+/* The graph surgery of node_fuse (c-t-simd.c:659-977) driven by the recorded walk. */
+static void apply_path(pg_graph* g, const char* b, int num, const pg_step* steps, int64_t n_steps, int end_col)
+{
+    const int len_b = (int)strlen(b);
     g->unsort = (int*)realloc(g->unsort, (size_t)(len_b + g->len) * sizeof(int));
 
     /* fresh linear chain for the sequence (c-t-simd.c:685-726) */
@@ -121,26 +180,11 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
         nd->out = (i + 1 < len_b) ? 1 : 0;
     }
 
-    int l = 0;
-    int num1 = g->len - 1, num2 = len_b - 1, cont = 0, forced = -1;
-    /* start at the best sink: max lastsorce, the lowest sort index wins ties, index 0 is never looked at
-     * (c-t-simd.c:737-750) */
-    {
-        int s1 = INT_MIN, seen = 0;
-        for (int i = g->len - 1; i > 0; i--) {
-            const pg_node* nd = &g->nodes[g->sort[i]];
-            if (nd->out == 0) {
-                if (s1 <= lastscore[i]) { s1 = lastscore[i]; num1 = nd->sub; }
-                seen++;
-            }
-            if (seen >= g->last_node_num) break;
-        }
-    }
-
-    while (num1 != -1 && num2 != -1) {
+    int l = 0, cont = 0;
+    for (int64_t si = 0; si < n_steps; si++) {
+        const int num1 = steps[si].node, num2 = steps[si].col;
+        const int code = steps[si].code, peek = steps[si].peek;
         const int R = g->sort[num1];
-        int code;
-        if (forced >= 0) { code = forced; forced = -1; } else code = SRC(num1, num2);
         const int kind = code / 42, pidx = code % 42;
         const int P = g->nodes[R].pre[pidx];
         const int Psub = sub_of(g, P);
@@ -149,25 +193,12 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
             cont = 0;
             become_member(g, seq[num2], num, g->len + l, 1);
             l++;
-            const int fs = FSRC(num1, num2);
-            if (num2 - 1 > 0 && (iabs(fs) == 1 || (iabs(fs) == 2 && FSRC(num1, num2 - 1) < 0))) forced = 126;
-            num2--;
             continue;
         }
-        if (kind == 0) {                                   /* E: graph node R is skipped (:773-785) */
-            cont = 3;
-            const int es = ESRC(num1, num2);
-            if (Psub > 0 && ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && ESRC(Psub, num2) < 0))) {
-                int s5 = ESRC(Psub, num2) % 42;
-                forced = iabs(s5) - 1;
-            }
-            num1 = Psub;
-            continue;
-        }
+        if (kind == 0) { cont = 3; continue; }             /* E: graph node R is skipped (:773-785) */
         if (kind == 1) {                                   /* match: the character fuses into R (:786-860) */
             if (num2 == len_b - 1) {
-                const int reuse = (Psub >= 0 && num2 - 1 >= 0 && SRC(Psub, num2 - 1) / 42 == 1);
-                if (reuse) g->nodes[R].ew[pidx]++;
+                if (peek) g->nodes[R].ew[pidx]++;
                 else if (num2 - 1 >= 0) {
                     add_pre(g, R, seq[num2 - 1], 1);
                     pg_node* pv = &g->nodes[seq[num2 - 1]];
@@ -182,7 +213,7 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
                     nx->pre[nx->in - 1] = R;
                 }
             } else {
-                if (Psub != -1 && SRC(Psub, num2 - 1) / 42 == 1) g->nodes[R].ew[pidx]++;
+                if (Psub != -1 && peek) g->nodes[R].ew[pidx]++;
                 else {
                     add_pre(g, R, seq[num2 - 1], 1);
                     pg_node* pv = &g->nodes[seq[num2 - 1]];
@@ -197,8 +228,6 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
             }
             cont = 1;
             g->nodes[R].pass[num] = 1;
-            num1 = Psub;
-            num2--;
             continue;
         }
         /* mismatch: the character is aligned to R's column (:861-956) */
@@ -209,7 +238,7 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
                 if (g->nodes[seq[num2]].base != g->nodes[Mn].base) continue;
                 int reused = 0;
                 if (num2 != 0) {
-                    if (Psub != -1 && SRC(Psub, num2 - 1) / 42 == 1) {
+                    if (Psub != -1 && peek) {
                         for (int ss = 0; ss < g->nodes[Mn].in; ss++)
                             if (g->nodes[Mn].pre[ss] == P) { g->nodes[Mn].ew[ss]++; reused = 1; }
                     }
@@ -252,53 +281,73 @@ static void node_fuse(pg_graph* g, const char* b, int num, const int8_t* source,
                     x->ring[s] = r->ring[s];
                 }
             }
-            num1 = Psub;
-            num2--;
         }
     }
-    while (num2 > -1) {                                    /* leftover prefix: new nodes (:959-972) */
+    for (int num2 = end_col; num2 > -1; num2--) {          /* leftover prefix: new nodes (:959-972) */
         become_member(g, seq[num2], num, g->len + l, 0);
         l++;
-        num2--;
     }
     g->len += l;
     g->unsort = (int*)realloc(g->unsort, (size_t)g->len * sizeof(int));
     g->sort = (int*)realloc(g->sort, (size_t)g->len * sizeof(int));
     free(seq);
-#undef SRC
-#undef ESRC
-#undef FSRC
 }
 
 /* ------------------------------------------------------------------------------ control (c-t-simd.c:979-1049) */
 
+static void build_csr(const pg_graph* g, int32_t** pred_off, int32_t** pred, uint8_t** base, uint8_t** is_sink)
+{
+    const int V = g->len;
+    *pred_off = (int32_t*)malloc((size_t)(V + 1) * sizeof(int32_t));
+    size_t npred = 0;
+    for (int r = 0; r < V; r++) npred += (size_t)g->nodes[g->sort[r]].in;
+    *pred = (int32_t*)malloc((npred ? npred : 1) * sizeof(int32_t));
+    *base = (uint8_t*)malloc((size_t)(V > 0 ? V : 1));
+    *is_sink = (uint8_t*)malloc((size_t)(V > 0 ? V : 1));
+    (*pred_off)[0] = 0;
+    for (int r = 0; r < V; r++) {                          /* CSR of the DAG in p->sort[] order, predecessors in pre[] order */
+        const pg_node* nd = &g->nodes[g->sort[r]];
+        (*base)[r] = nd->base;
+        (*is_sink)[r] = (nd->out == 0);
+        int k = (*pred_off)[r];
+        for (int j = 0; j < nd->in; j++) (*pred)[k++] = sub_of(g, nd->pre[j]);
+        (*pred_off)[r + 1] = k;
+    }
+}
+
 int pg_align_and_fuse(pg_graph* g, const char* seq, int num, pg_fill_fn fill, void* ctx)
 {
     const int V = g->len, n = (int)strlen(seq);
-    int32_t* pred_off = (int32_t*)malloc((size_t)(V + 1) * sizeof(int32_t));
-    size_t npred = 0;
-    for (int r = 0; r < V; r++) npred += (size_t)g->nodes[g->sort[r]].in;
-    int32_t* pred = (int32_t*)malloc((npred ? npred : 1) * sizeof(int32_t));
-    uint8_t* base = (uint8_t*)malloc((size_t)(V > 0 ? V : 1));
-    uint8_t* is_sink = (uint8_t*)malloc((size_t)(V > 0 ? V : 1));
-    pred_off[0] = 0;
-    for (int r = 0; r < V; r++) {                          /* CSR of the DAG in p->sort[] order, predecessors in pre[] order */
-        const pg_node* nd = &g->nodes[g->sort[r]];
-        base[r] = nd->base;
-        is_sink[r] = (nd->out == 0);
-        int k = pred_off[r];
-        for (int j = 0; j < nd->in; j++) pred[k++] = sub_of(g, nd->pre[j]);
-        pred_off[r + 1] = k;
-    }
+    int32_t *pred_off, *pred; uint8_t *base, *is_sink;
+    build_csr(g, &pred_off, &pred, &base, &is_sink);
     const size_t cells = (size_t)V * (size_t)n;
     int8_t* source = (int8_t*)malloc(cells ? cells : 1);
     int8_t* esource = (int8_t*)malloc(cells ? cells : 1);
     int8_t* fsource = (int8_t*)malloc(cells ? cells : 1);
     int32_t* lastscore = (int32_t*)calloc((size_t)(V > 0 ? V : 1), sizeof(int32_t));
     int rc = fill(ctx, V, pred_off, pred, base, is_sink, (const uint8_t*)seq, n, source, esource, fsource, lastscore);
-    if (rc == 0) node_fuse(g, seq, num, source, esource, fsource, lastscore);
+    if (rc == 0) {
+        int64_t ns = 0; int32_t end_col = -1;
+        pg_step* steps = walk_arrays(g, n, pred_off, pred, source, esource, fsource, lastscore, &ns, &end_col);
+        apply_path(g, seq, num, steps, ns, end_col);
+        free(steps);
+    }
     free(pred_off); free(pred); free(base); free(is_sink);
     free(source); free(esource); free(fsource); free(lastscore);
+    return rc;
+}
+
+int pg_align_and_fuse_path(pg_graph* g, const char* seq, int num, pg_path_fn path, void* ctx)
+{
+    const int V = g->len, n = (int)strlen(seq);
+    int32_t *pred_off, *pred; uint8_t *base, *is_sink;
+    build_csr(g, &pred_off, &pred, &base, &is_sink);
+    pg_step* steps = NULL; int64_t ns = 0; int32_t end_col = -1;
+    void (*free_steps)(void*) = free;
+    int rc = path(ctx, V, pred_off, pred, base, is_sink, (const uint8_t*)seq, n, &steps, &ns, &end_col, &free_steps);
+    if (rc == 0) apply_path(g, seq, num, steps, ns, end_col);
+    if (steps) free_steps(steps);
+    free(pred_off); free(pred); free(base); free(is_sink);
     return rc;
 }
 

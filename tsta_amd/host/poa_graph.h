@@ -41,8 +41,21 @@ typedef int (*pg_fill_fn)(void* ctx, int n_nodes, const int32_t* pred_off, const
                           const uint8_t* is_sink, const uint8_t* seq, int32_t n, int8_t* source, int8_t* esource,
                           int8_t* fsource, int32_t* lastscore);
 
+/* One visited cell of the traceback walk of node_fuse (c-t-simd.c:751-957): sort index of the node, sequence
+ * position, the EFFECTIVE trace code there (after the forced-continuation overwrites, :767-769, :776-782) and, for
+ * match / mismatch cells, whether the diagonal predecessor cell is itself a match (:790, :827, :873), which is all
+ * the graph surgery needs to know about the trace arrays.  Same layout as tsta_poa_step (include/tsta_engine.h). */
+typedef struct pg_step { int32_t node, col; int8_t code, peek; int16_t pad; } pg_step;
+
+/* The walk done elsewhere (on the GPU, next to the trace arrays): returns malloc'd steps (freed by the caller with
+ * free_steps), their count and the sequence position at which the walk stopped (-1 if the sequence was consumed). */
+typedef int (*pg_path_fn)(void* ctx, int n_nodes, const int32_t* pred_off, const int32_t* pred, const uint8_t* base,
+                          const uint8_t* is_sink, const uint8_t* seq, int32_t n, pg_step** steps, int64_t* n_steps,
+                          int32_t* end_col, void (**free_steps)(void*));
+
 pg_graph* pg_build_init(const char* s0, int sum);
 int       pg_align_and_fuse(pg_graph* g, const char* seq, int num, pg_fill_fn fill, void* ctx);
+int       pg_align_and_fuse_path(pg_graph* g, const char* seq, int num, pg_path_fn path, void* ctx);
 void      pg_sort(pg_graph* g, int final_pass);
 void      pg_write_result(pg_graph* g, int num, FILE* out);
 void      pg_free(pg_graph* g);
