@@ -276,3 +276,17 @@ def test_error_paths(eng):
                             C.byref(ln)) == -5
     assert L.tsta_psa_align(eng._h, C.byref(prm), p(seq), -3, p(seq), 4, C.byref(ms), C.byref(ra), C.byref(rb), C.byref(ln)) == -1
     assert b"invalid" in L.tsta_strerror(-1)
+
+
+def test_few_long_pairs_use_the_pipelined_single_pair_fill(eng):
+    # <= 64 pairs, each >= 2e8 cells: scored by the multi-wave single-pair fill (psa_trace.hip, TRACE=false)
+    x = util.random_dna(555, 21_000)
+    pairs = [(x, _fixed_len(util.mutate(x, 556, 0.06), 15_000, 3)),
+             (util.random_dna(557, 14_500), util.random_dna(558, 20_011)),        # shorter first: swapped
+             (x, x.copy())]
+    got = eng.psa_score_batch(pairs)
+    want = util.oracle_maxscore_batch(pairs, threads=3)
+    assert np.array_equal(got, want)
+    for sc in (dict(M=10, X=-10, E=-3, O=-12), dict(M=1, X=-1, E=-1, O=0)):
+        got = eng.psa_score_batch(pairs[:2], tsta_amd.Params(**sc))
+        assert np.array_equal(got, util.oracle_maxscore_batch(pairs[:2], threads=2, **sc))

@@ -43,6 +43,13 @@ struct PsaPackedArgs {
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream);
 int  psa_score_blocks_per_cu(int R);
 void launch_dpp_selftest(int* d_out, hipStream_t stream);
+
+struct Engine;
+}  // namespace tsta
+struct tsta_params;
+namespace tsta {
+// psa_trace.hip: score-only fill of ONE oriented pair pipelined over many waves (host pointers; synchronous)
+int psa_score_single_pair(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m, int32_t* maxscore);
 void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream);
 int  psa_packed_blocks_per_cu(int R);
 

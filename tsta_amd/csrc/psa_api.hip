@@ -155,6 +155,21 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     const size_t nb = (size_t)n_pairs;
+    // A handful of long pairs: the batch kernels give each pair one wave, which leaves the chip idle; run every such
+    // pair through the pipelined single-pair fill (the bands of one pair spread over many waves) instead.
+    if (n_pairs <= 64) {
+        bool all_big = true;
+        for (int64_t k = 0; k < n_pairs; ++k) all_big = all_big && (int64_t)len1[k] * len2[k] >= 200000000LL;
+        if (all_big) {
+            for (int64_t k = 0; k < n_pairs; ++k) {
+                const bool swap = len2[k] > len1[k];                                   // psa.c:194-199
+                const uint8_t* a = seqs + (swap ? off2[k] : off1[k]); const int n = swap ? len2[k] : len1[k];
+                const uint8_t* b = seqs + (swap ? off1[k] : off2[k]); const int m = swap ? len1[k] : len2[k];
+                if ((rc = tsta::psa_score_single_pair(e, p, a, n, b, m, &out[k])) != TSTA_OK) return rc;
+            }
+            return TSTA_OK;
+        }
+    }
     // Order the pairs by oriented geometry (columns n, rows m) so that pairs of equal / similar size sit next to each
     // other and can share a wave in the packed kernel (couples are adjacent pairs, the smaller one is padded to the
     // larger); results are scattered back to the caller's order.

@@ -66,7 +66,7 @@ struct TLane {
 
 // one DP step of the lane's R rows; returns the R trace bytes packed little-endian into `tb` (R<=4: one dword,
 // R==8: two dwords)
-template <int R, bool PRED>
+template <int R, bool PRED, bool TRACE>
 __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int lane, const int n, const int nvalid,
                                            const int M, const int X, const int E, const int O, unsigned (&tb)[(R + 3) / 4])
 {
@@ -91,13 +91,14 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
         const int dg = d + (s.cch == s.bch[k] ? M : X);
         h = max3i(dg, e, f);
         const int g = h + O;
-        // trace code (see file header)
-        const int nd = min(h - dg, 1);
-        const int nf = min(h - f, 1);
-        const int fge = min(max(g - f, -1), 1) + 1;
-        const int ege = min(max(g - e, -1), 1) + 1;
-        const unsigned code = (unsigned)(nd | (nf << 1) | (fge << 2) | (ege << 4));
-        tb[k / 4] |= code << (8 * (k % 4));
+        if (TRACE) {                                        // trace code (see file header)
+            const int nd = min(h - dg, 1);
+            const int nf = min(h - f, 1);
+            const int fge = min(max(g - f, -1), 1) + 1;
+            const int ege = min(max(g - e, -1), 1) + 1;
+            const unsigned code = (unsigned)(nd | (nf << 1) | (fge << 2) | (ege << 4));
+            tb[k / 4] |= code << (8 * (k % 4));
+        }
         const int eb = max(e, g);
         const int fbn = max(f, g);
         d = s.hl[k];
@@ -118,7 +119,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
 }
 
-template <int R, bool PRED>
+template <int R, bool PRED, bool TRACE>
 __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                             const int M, const int X, const int E, const int O, uint4* __restrict__ tq)
 {
@@ -130,16 +131,17 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
 #pragma unroll
         for (int q = 0; q < SPB; ++q) {
             unsigned tb[(R + 3) / 4];
-            trace_step<R, PRED>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
-            if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
+            trace_step<R, PRED, TRACE>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
+            if constexpr (!TRACE) { (void)acc; }
+            else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
             else { acc[(q * R) / 4] |= tb[0] << (8 * ((q * R) % 4)); }
         }
-        tq[(size_t)g * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        if (TRACE) tq[(size_t)g * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
-template <int R>
+template <int R, bool TRACE>
 __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
 {
     constexpr int NS = TraceCfg<R>::NS;
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         if (c < n) { nt = top[c]; na = A.a[c]; }
         s.th = nt.x; s.te = nt.y; s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
-        if (t0 >= 64 && t0 + 63 < n) trace_block<R, false>(s, t0, lane, n, nvalid, M, X, E, O, tq);
-        else                         trace_block<R, true>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else                         trace_block<R, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq);
         const int cs = t0 - 64 + lane;
         if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
     }
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(WalkArgs A)
     if (lane == 0) { A.out[2] = cnt; A.out[3] = i; A.out[4] = j; }
 }
 
-template <int R>
+// TRACE = true: fill with packed trace + on-device walk (tsta_psa_align).  TRACE = false: the same pipelined fill of
+// ONE pair over many waves, score only (a single long pair would otherwise occupy one wave of the batch kernel).
+template <int R, bool TRACE>
 static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m,
                      int32_t* maxscore, int32_t* end_score, std::vector<uint8_t>& ops, int& fi, int& fj)
 {
@@ -350,8 +354,8 @@ static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, c
     if ((rc = e->reserve(e->in_seqs, (size_t)n + m + 64, "hipMalloc(seqs)")) ||
         (rc = e->reserve(e->rows, (size_t)(W + 1) * row_stride * sizeof(int2), "hipMalloc(rows)")) ||
         (rc = e->reserve(e->scratch, (size_t)W * NS * 64 * sizeof(int), "hipMalloc(state)")) ||
-        (rc = e->reserve(e->trace, (size_t)W * band_bytes, "hipMalloc(trace)")) ||
-        (rc = e->reserve(e->scratch2, (size_t)n + m + 64, "hipMalloc(ops)")))
+        (TRACE && (rc = e->reserve(e->trace, (size_t)W * band_bytes, "hipMalloc(trace)"))) ||
+        (TRACE && (rc = e->reserve(e->scratch2, (size_t)n + m + 64, "hipMalloc(ops)"))))
         return rc;
     uint8_t* d_a = reinterpret_cast<uint8_t*>(e->in_seqs.p);
     uint8_t* d_b = d_a + n;
@@ -381,14 +385,14 @@ static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, c
         if (w_lo >= w_hi) continue;
         A.d = (int)d; A.w_lo = (int)w_lo; A.w_hi = (int)w_hi;
         const int blocks = (int)((w_hi - w_lo + 3) / 4);
-        hipLaunchKernelGGL(psa_trace_tile_kernel<R>, dim3(blocks), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3(blocks), dim3(256), 0, s, A);
         ++launches;
     }
     hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(1), dim3(256), 0, s, A.state, W, m, d_out);
     WalkArgs Wk;
     Wk.trace = A.trace; Wk.band_bytes = band_bytes; Wk.n = n; Wk.m = m;
     Wk.ops = reinterpret_cast<uint8_t*>(e->scratch2.p); Wk.out = d_out;
-    hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(1), dim3(64), 0, s, Wk);
+    if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(1), dim3(64), 0, s, Wk);
     launches += 2;
     e->n_launches = launches;
     e->timing_end(s);
@@ -398,11 +402,21 @@ static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, c
         (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
         return rc;
     *maxscore = h_out[0]; *end_score = h_out[1];
+    if (!TRACE) return TSTA_OK;
     const int cnt = h_out[2]; fi = h_out[3]; fj = h_out[4];
     if (cnt < 0 || cnt > n + m) { e->set_error("walker returned %d ops", cnt); return TSTA_ERR_INTERNAL; }
     ops.resize(cnt);
     if (cnt && (rc = e->check(hipMemcpy(ops.data(), Wk.ops, cnt, hipMemcpyDeviceToHost), "D2H ops"))) return rc;
     return TSTA_OK;
+}
+
+// Score-only fill of ONE oriented pair (a = columns, b = rows; host pointers) spread over the whole chip.
+int psa_score_single_pair(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m, int32_t* maxscore)
+{
+    std::vector<uint8_t> ops;
+    int fi = 0, fj = 0;
+    int32_t es = 0;
+    return run_align<4, false>(e, p, a, n, b, m, maxscore, &es, ops, fi, fj);
 }
 
 }  // namespace tsta
@@ -430,8 +444,8 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
         // rows per lane: small bands expose more concurrent bands of the single pair
         const int R_env = e->opt_trace_rows;                                                    // knob "trace_rows"
         const int Rsel = (R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
-        if (Rsel == 4) rc = run_align<4>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
-        else           rc = run_align<2>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
+        if (Rsel == 4) rc = run_align<4, true>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
+        else           rc = run_align<2, true>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
         if (rc != TSTA_OK) return rc;
     }
     // psa.c:464-516: leftover prefix of a against gaps, leftover prefix of b against gaps, then reverse
