@@ -30,7 +30,7 @@ from tsta_amd.sharding import gather_scores  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 int32 lane-ops/s
-VALU_OPS_PER_CELL = 6.53              # K1p hot loop: 209 VALU instructions per 32 cells (6 v_pk_max/min + 6 add/sub/xor per 2 cells + 8 DPP + moves per step)
+VALU_OPS_PER_CELL = 6.09              # K1p hot loop: 195 VALU instructions per step of 32 cells (5.5 per cell: 6 v_pk_max/min + 5 add/sub/xor per 2 cells; + 8 DPP, moves, running max per step)
 
 
 def parse():
