@@ -18,16 +18,20 @@ struct PsaBatchArgs {
     int64_t        n_pairs;
     int32_t        M, X, E, O;
     unsigned long long* clock_out;   // diagnostics only (TSTA_PSA_CLOCK=1): {memtime, memrealtime} x {begin, end} of wave 0
-    int64_t        packed_couples;  // couples (2c, 2c+1), c < packed_couples, are tried by the packed kernel first
+    int64_t        packed_couples;  // couples of positions (2c, 2c+1), c < packed_couples, are tried by the packed kernel first
+    const uint32_t* order;          // position -> pair index (pairs ordered by geometry so neighbours are similar); NULL = identity
 };
 
-// A couple of adjacent pairs (2c, 2c+1) goes to the packed-int16 kernel iff both are non-empty and padding the
+__host__ __device__ inline int64_t psa_pair_at(const uint32_t* order, int64_t pos) { return order ? (int64_t)order[pos] : pos; }
+
+// The couple at positions (2c, 2c+1) of the geometry order goes to the packed-int16 kernel iff both are non-empty and padding the
 // smaller one to the larger one's geometry (columns n = longer sequence, rows m = shorter) still beats scoring them
 // separately with the int32 kernel: the packed kernel needs ~0.63x the instructions per (padded) cell pair, so the
 // padded area must stay below ~0.8x the two areas together.  Evaluated identically by both kernels.
-__host__ __device__ inline bool psa_couple_is_packed(const int32_t* len1, const int32_t* len2, int64_t c)
+__host__ __device__ inline bool psa_couple_is_packed(const int32_t* len1, const int32_t* len2, const uint32_t* order, int64_t c)
 {
-    const int32_t a1 = len1[2 * c], a2 = len2[2 * c], b1 = len1[2 * c + 1], b2 = len2[2 * c + 1];
+    const int64_t pa = psa_pair_at(order, 2 * c), pb = psa_pair_at(order, 2 * c + 1);
+    const int32_t a1 = len1[pa], a2 = len2[pa], b1 = len1[pb], b2 = len2[pb];
     const int64_t na = a1 > a2 ? a1 : a2, ma = a1 > a2 ? a2 : a1;
     const int64_t nb = b1 > b2 ? b1 : b2, mb = b1 > b2 ? b2 : b1;
     if (ma < 1 || mb < 1) return false;

@@ -1,5 +1,6 @@
 // psa_api.hip — C-ABI entry points for the PSA kernels (score-only batch).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +38,38 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int m
     if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
     if (fits(16)) return 16;
     return fits(8) ? 8 : 0;
+}
+
+// geometry key of a pair: (columns n = longer sequence) << 32 | (rows m = shorter)
+__global__ void psa_geometry_keys_kernel(const int32_t* len1, const int32_t* len2, int64_t n_pairs, uint64_t* keys, uint32_t* idx)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pairs) return;
+    const uint32_t a = (uint32_t)len1[k], b = (uint32_t)len2[k];
+    keys[k] = ((uint64_t)(a > b ? a : b) << 32) | (a > b ? b : a);
+    idx[k] = (uint32_t)k;
+}
+
+// Orders the pairs of a device-resident batch by geometry (radix sort of 64-bit keys, rocPRIM via hipCUB) so that
+// pairs of equal / similar size become neighbours and can share a wave in the packed kernel.  Returns the device
+// permutation (position -> pair index) in e->scratch, or nullptr on failure (callers then use the identity order).
+static const uint32_t* psa_order_by_geometry(Engine* e, const int32_t* d_len1, const int32_t* d_len2, int64_t n_pairs, hipStream_t s)
+{
+    const size_t n = (size_t)n_pairs;
+    size_t temp_bytes = 0;
+    uint64_t* kdummy = nullptr; uint32_t* vdummy = nullptr;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, kdummy, kdummy, vdummy, vdummy, (int)n_pairs, 0, 64, s) != hipSuccess) return nullptr;
+    const size_t kb = (n * 8 + 255) / 256 * 256, vb = (n * 4 + 255) / 256 * 256;
+    if (e->reserve(e->scratch, 2 * kb + 2 * vb + temp_bytes + 256, "hipMalloc(geometry order)") != TSTA_OK) return nullptr;
+    char* base = reinterpret_cast<char*>(e->scratch.p);
+    uint64_t* k_in = reinterpret_cast<uint64_t*>(base);
+    uint64_t* k_out = reinterpret_cast<uint64_t*>(base + kb);
+    uint32_t* v_in = reinterpret_cast<uint32_t*>(base + 2 * kb);
+    uint32_t* v_out = reinterpret_cast<uint32_t*>(base + 2 * kb + vb);
+    void* temp = base + 2 * kb + 2 * vb;
+    hipLaunchKernelGGL(psa_geometry_keys_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, d_len1, d_len2, n_pairs, k_in, v_in);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n_pairs, 0, 64, s) != hipSuccess) return nullptr;
+    return v_out;
 }
 
 }  // namespace tsta
@@ -83,6 +116,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     a.counter = reinterpret_cast<unsigned int*>(e->counter.p);
     a.n_pairs = n_pairs; a.M = p->M; a.X = p->X; a.E = p->E; a.O = p->O;
     a.packed_couples = couples;
+    a.order = couples ? tsta::psa_order_by_geometry(e, d_len1, d_len2, n_pairs, s) : nullptr;
     static const bool want_clock = getenv("TSTA_PSA_CLOCK") != nullptr;      // diagnostics: in-kernel shader clock
     a.clock_out = want_clock ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->counter.p) + 64) : nullptr;
 
@@ -170,24 +204,9 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
             return TSTA_OK;
         }
     }
-    // Order the pairs by oriented geometry (columns n, rows m) so that pairs of equal / similar size sit next to each
-    // other and can share a wave in the packed kernel (couples are adjacent pairs, the smaller one is padded to the
-    // larger); results are scattered back to the caller's order.
-    std::vector<int64_t> perm(nb);
-    for (size_t k = 0; k < nb; ++k) perm[k] = (int64_t)k;
-    auto key = [&](int64_t k) {
-        const int32_t a = len1[k], b = len2[k];
-        return ((uint64_t)(uint32_t)std::max(a, b) << 32) | (uint32_t)std::min(a, b);
-    };
-    bool sorted_already = true;
-    for (size_t k = 1; k < nb && sorted_already; ++k) sorted_already = key((int64_t)k - 1) <= key((int64_t)k);
-    if (!sorted_already) std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
     std::vector<int64_t> h_off(2 * nb);
     std::vector<int32_t> h_len(2 * nb);
-    for (size_t k = 0; k < nb; ++k) {
-        h_off[k] = off1[perm[k]]; h_off[nb + k] = off2[perm[k]];
-        h_len[k] = len1[perm[k]]; h_len[nb + k] = len2[perm[k]];
-    }
+    for (size_t k = 0; k < nb; ++k) { h_off[k] = off1[k]; h_off[nb + k] = off2[k]; h_len[k] = len1[k]; h_len[nb + k] = len2[k]; }
     const size_t meta_bytes = nb * (2 * sizeof(int64_t) + 2 * sizeof(int32_t));
     if ((rc = e->reserve(e->in_seqs, (size_t)seqs_bytes + 16, "hipMalloc(seqs)")) != TSTA_OK) return rc;
     if ((rc = e->reserve(e->in_meta, meta_bytes, "hipMalloc(meta)")) != TSTA_OK) return rc;
@@ -205,11 +224,8 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     rc = tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                   d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
-    std::vector<int32_t> h_out(nb);
-    if ((rc = e->check(hipMemcpyAsync(h_out.data(), e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
-    if ((rc = e->check(hipStreamSynchronize(s), "psa_score_batch sync"))) return rc;
-    for (size_t k = 0; k < nb; ++k) out[perm[k]] = h_out[k];
-    return TSTA_OK;
+    if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
+    return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
 }
 
 }  // extern "C"

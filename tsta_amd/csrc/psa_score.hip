@@ -163,18 +163,19 @@ __global__ __launch_bounds__(256) void psa_score_batch_kernel(PsaBatchArgs A)
         if (lane == 0) ticket = atomicAdd(A.counter, 1u);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if ((int64_t)ticket >= A.n_pairs) break;               // every wave reaches this exit
-        if ((int64_t)(ticket >> 1) < A.packed_couples && psa_couple_is_packed(A.len1, A.len2, ticket >> 1))
+        if ((int64_t)(ticket >> 1) < A.packed_couples && psa_couple_is_packed(A.len1, A.len2, A.order, ticket >> 1))
             continue;                                           // scored by the packed-int16 kernel
-        const int l1 = A.len1[ticket], l2 = A.len2[ticket];
-        const uint8_t* s1 = A.seqs + A.off1[ticket];
-        const uint8_t* s2 = A.seqs + A.off2[ticket];
+        const int64_t pi = psa_pair_at(A.order, ticket);
+        const int l1 = A.len1[pi], l2 = A.len2[pi];
+        const uint8_t* s1 = A.seqs + A.off1[pi];
+        const uint8_t* s2 = A.seqs + A.off2[pi];
         // psa.c:194-199: the strictly longer sequence becomes seq[0] (columns)
         const bool swap = l2 > l1;
         const uint8_t* a = swap ? s2 : s1; const int n = swap ? l2 : l1;
         const uint8_t* b = swap ? s1 : s2; const int m = swap ? l1 : l2;
         int ms = kNegInf;
         if (m > 0 && n > 0) ms = psa_score_pair<R>(a, n, b, m, row, lane, A.M, A.X, A.E, A.O);
-        if (lane == 0) A.out[ticket] = max(ms, -100);           // ms = MIN (-100) floor, psa.c:110,590
+        if (lane == 0) A.out[pi] = max(ms, -100);               // ms = MIN (-100) floor, psa.c:110,590
         wave_mem_sync();                                        // row buffer is reused by the next pair
     }
     if (stamp) { A.clock_out[2] = __builtin_amdgcn_s_memtime(); A.clock_out[3] = __builtin_amdgcn_s_memrealtime(); }

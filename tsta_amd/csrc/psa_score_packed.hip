@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         if (lane == 0) ticket = atomicAdd(A.counter, 1u);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if ((int64_t)ticket >= A.packed_couples) break;         // every wave reaches this exit
-        if (!psa_couple_is_packed(A.len1, A.len2, ticket)) continue;   // K1 (int32) takes these two pairs
-        const int64_t pa = 2 * (int64_t)ticket, pb = pa + 1;
+        if (!psa_couple_is_packed(A.len1, A.len2, A.order, ticket)) continue;   // K1 (int32) takes these two pairs
+        const int64_t pa = psa_pair_at(A.order, 2 * (int64_t)ticket), pb = psa_pair_at(A.order, 2 * (int64_t)ticket + 1);
         const int l1a = A.len1[pa], l2a = A.len2[pa], l1b = A.len1[pb], l2b = A.len2[pb];
         const uint8_t* s1a = A.seqs + A.off1[pa]; const uint8_t* s2a = A.seqs + A.off2[pa];
         const uint8_t* s1b = A.seqs + A.off1[pb]; const uint8_t* s2b = A.seqs + A.off2[pb];
