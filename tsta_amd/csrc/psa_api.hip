@@ -129,7 +129,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         pa.b.rows = a.rows + need32 / sizeof(int2);
         pa.b.counter = a.counter + 1;
         pa.b.clock_out = nullptr;
-        if (want_clock && e->reserve(e->scratch2, (size_t)(8 + 2 * pblocks) * 8 + 64, "diag") == TSTA_OK)
+        if (want_clock && e->reserve(e->scratch2, 256, "diag") == TSTA_OK)
             pa.b.clock_out = reinterpret_cast<unsigned long long*>(e->scratch2.p);
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         pa.pe = ae | (ae << 16); pa.po = ao | (ao << 16); pa.pm = am | (am << 16); pa.pmx = amx | (amx << 16);
@@ -146,21 +146,6 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
             hipStreamSynchronize(s) == hipSuccess && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, R, (long long)blocks);
-        if (couples && e->scratch2.p) {
-            std::vector<unsigned long long> st(8 + 2 * pblocks);
-            if (hipMemcpy(st.data(), e->scratch2.p, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                unsigned long long t0 = ~0ull;
-                for (int64_t b = 0; b < pblocks; ++b) t0 = std::min(t0, st[8 + b]);
-                int hist[8] = {0}; double last_end = 0;
-                for (int64_t b = 0; b < pblocks; ++b) {
-                    const double ms = (double)(st[8 + b] - t0) / 1e5;
-                    hist[std::min(7, (int)(ms / 250.0))]++;
-                    last_end = std::max(last_end, (double)(st[8 + pblocks + b] - t0) / 1e5);
-                }
-                fprintf(stderr, "[tsta] packed block start histogram (250 ms bins): %d %d %d %d %d %d %d %d; last end %.1f ms\n",
-                        hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], last_end);
-            }
-        }
         if (couples && e->scratch2.p && hipMemcpy(h, e->scratch2.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score_packed wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks, %d blocks/CU by API)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, Rp, (long long)pblocks,

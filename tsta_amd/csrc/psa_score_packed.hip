@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
     int2* rowB = rowA + A.row_stride;
     const bool stamp = A.clock_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (stamp) { A.clock_out[0] = __builtin_amdgcn_s_memtime(); A.clock_out[1] = __builtin_amdgcn_s_memrealtime(); }
-    if (A.clock_out != nullptr && threadIdx.x == 0) A.clock_out[8 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         unsigned int ticket = 0;
         if (lane == 0) ticket = atomicAdd(A.counter, 1u);
@@ -266,7 +265,6 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         wave_mem_sync();
     }
     if (stamp) { A.clock_out[2] = __builtin_amdgcn_s_memtime(); A.clock_out[3] = __builtin_amdgcn_s_memrealtime(); }
-    if (A.clock_out != nullptr && threadIdx.x == 0) A.clock_out[8 + gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream)
