@@ -121,6 +121,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # rehearsal of the N>1 control flow on a box with ONE GPU (never used by the driver): every rank computes on device 0
+    # and the collectives run over gloo on host copies.  Numbers from such a run mean nothing.
+    rehearsal = os.environ.get("TSTA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -129,7 +134,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     P, L = args.pairs_per_gpu, args.len
     eng = tsta_amd.Engine(local_rank)
@@ -149,7 +157,8 @@ def main():
         if i is not None:
             ev[i][1].record()
         if world > 1:
-            gathered[0] = gather_scores(scores, P * world)     # the path's only collective: final score gather
+            # the path's only collective: final score gather (RCCL over xGMI; 4 B per pair)
+            gathered[0] = gather_scores(scores.cpu() if rehearsal else scores, P * world)
 
     torch.cuda.synchronize()
     with torch.cuda.stream(tstream):
@@ -166,7 +175,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -2,7 +2,7 @@
 """Large TSTA_msa check: runs the drop-in CLI (GPU) and, when present, the reference binary on the same generated
 family and compares the output files.  usage: msa_large_check.py N_SEQ LENGTH RATE"""
 import hashlib, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import util
 from tests.golden.make_poa_golden import family, write_multi_fasta

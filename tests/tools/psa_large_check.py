@@ -2,7 +2,7 @@
 """Large TSTA_psa check: drop-in CLI (GPU) vs the reference binary on the same generated pair: stdout + output file.
 usage: psa_large_check.py LENGTH RATE"""
 import hashlib, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import util
 length, rate = int(sys.argv[1]), float(sys.argv[2])
