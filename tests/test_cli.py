@@ -80,3 +80,19 @@ def test_cli_gz_crlf_swapped_inputs(built, tmp_path):
     ms, end, ra, rb = util.oracle_align(y, x)
     assert r.stdout == b"maxsorce=%d\n" % ms
     assert out.read_bytes() == b">1\n" + ra + b"\n>2\n" + rb
+
+
+@pytest.mark.gpu
+def test_batch_cli(built, tmp_path):
+    # TSTA_psa_batch: record k of -1 against record k of -2, ragged lengths, one `maxsorce=` line per pair
+    pairs = []
+    for i in range(40):
+        a = util.random_dna(700 + i, 200 + 37 * (i % 9))
+        pairs.append((a, util.mutate(a, 800 + i, 0.1)))
+    fa, fb = tmp_path / "a.fa", tmp_path / "b.fa"
+    fa.write_bytes(b"".join(b">a%d\n" % i + bytes(p[0]) + b"\n" for i, p in enumerate(pairs)))
+    fb.write_bytes(b"".join(b">b%d\n" % i + bytes(p[1]) + b"\n" for i, p in enumerate(pairs)))
+    r = run([os.path.join(built, "TSTA_psa_batch"), "-1", str(fa), "-2", str(fb)])
+    assert r.returncode == 0, r.stderr
+    want = util.oracle_maxscore_batch(pairs)
+    assert r.stdout == b"".join(b"maxsorce=%d\n" % w for w in want)

@@ -1,0 +1,58 @@
+/* cli_psa_batch.c — batch front-end the reference does not have: scores record k of the -1
+ * multi-FASTA against record k of the -2 multi-FASTA, all pairs in ONE tsta_psa_score_batch call (packed kernel,
+ * pairs ordered by geometry on the device).  Same scoring flags as TSTA_psa_notrace; prints one line per pair,
+ * "maxsorce=%d" exactly as the reference prints it for a single pair (psa.c:666).
+ *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O]        env TSTA_DEVICE = GPU index */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "../../include/tsta_engine.h"
+#include "fasta.h"
+
+int main(int argc, char* argv[])
+{
+    tsta_params prm = {2, -5, -2, -4};
+    const char *input1 = NULL, *input2 = NULL;
+    int c;
+    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:")) != -1) {
+        switch (c) {
+            case 'M': prm.M = atoi(optarg); break;
+            case 'X': prm.X = atoi(optarg); break;
+            case 'E': prm.E = atoi(optarg); break;
+            case 'O': prm.O = atoi(optarg); break;
+            case 'T': case 'W': break;
+            case '1': input1 = optarg; break;
+            case '2': input2 = optarg; break;
+            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4]\n"); return 2;
+        }
+    }
+    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4]\n"); return 2; }
+    fasta_file* f1 = fasta_read(input1, 0);
+    fasta_file* f2 = fasta_read(input2, 0);
+    if (f1->count != f2->count) { fprintf(stderr, "record counts differ: %zu vs %zu\n", f1->count, f2->count); return 1; }
+    const size_t n = f1->count;
+    size_t total = 0;
+    for (size_t k = 0; k < n; k++) total += f1->seqs[k].length + f2->seqs[k].length;
+    uint8_t* seqs = (uint8_t*)malloc(total ? total : 1);
+    int64_t* off1 = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t)); int64_t* off2 = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t));
+    int32_t* len1 = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t)); int32_t* len2 = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    int32_t* out = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    size_t pos = 0;
+    for (size_t k = 0; k < n; k++) {
+        off1[k] = (int64_t)pos; len1[k] = (int32_t)f1->seqs[k].length; memcpy(seqs + pos, f1->seqs[k].data, f1->seqs[k].length); pos += f1->seqs[k].length;
+        off2[k] = (int64_t)pos; len2[k] = (int32_t)f2->seqs[k].length; memcpy(seqs + pos, f2->seqs[k].data, f2->seqs[k].length); pos += f2->seqs[k].length;
+    }
+    const char* dev = getenv("TSTA_DEVICE");
+    tsta_engine* eng = NULL;
+    int rc = tsta_engine_create(dev ? atoi(dev) : 0, &eng);
+    if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
+    rc = tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
+    if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+    for (size_t k = 0; k < n; k++) printf("maxsorce=%d\n", out[k]);
+    tsta_engine_destroy(eng);
+    fasta_free(f1); fasta_free(f2);
+    free(seqs); free(off1); free(off2); free(len1); free(len2); free(out);
+    return 0;
+}
