@@ -90,3 +90,27 @@ def test_rows_per_lane_4_variant(eng):
             assert got == (o[0], o[2], o[3]), (l1, l2)
     finally:
         eng.set_option("trace_rows", 0); eng.set_option("trace_tile", 0)
+
+
+def test_fuzz_alignment_vs_oracle(eng):
+    # random scoring sets (including zero / positive-ish corner values) x random pairs: full output strings vs trace()
+    rng = np.random.default_rng(77)
+    for trial in range(60):
+        M = int(rng.integers(0, 9)); X = int(rng.integers(-12, max(M, 1))); E = int(rng.integers(-6, 1)); O = int(rng.integers(-14, 1))
+        n = int(rng.integers(1, 1400)); m = int(rng.integers(1, 1400))
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = trial % 4
+        if kind == 0:
+            b = util.mutate(a, int(rng.integers(1 << 30)), 0.02 + 0.3 * rng.random())[:m]
+        elif kind == 1:
+            b = util.random_dna(int(rng.integers(1 << 30)), m)
+        elif kind == 2:
+            b = util.low_complexity(int(rng.integers(1 << 30)), m, int(rng.integers(1, 4)))
+        else:
+            b = np.concatenate([a[: n // 3], a[2 * n // 3:]])              # one long deletion
+        if len(b) == 0:
+            b = a[:1]
+        sc = dict(M=M, X=X, E=E, O=O)
+        got = eng.psa_align(a, b, tsta_amd.Params(**sc))
+        o = util.oracle_align(a, b, **sc)
+        assert got == (o[0], o[2], o[3]), (trial, sc, n, len(b))

@@ -290,3 +290,37 @@ def test_few_long_pairs_use_the_pipelined_single_pair_fill(eng):
     for sc in (dict(M=10, X=-10, E=-3, O=-12), dict(M=1, X=-1, E=-1, O=0)):
         got = eng.psa_score_batch(pairs[:2], tsta_amd.Params(**sc))
         assert np.array_equal(got, util.oracle_maxscore_batch(pairs[:2], threads=2, **sc))
+
+
+def test_fuzz_packed_vs_int32_vs_oracle(eng):
+    # random scoring sets inside the packed kernel's domain x random ragged batches: packed R=16, packed R=8 and the int32
+    # kernel must agree on every pair (GPU vs GPU, so the batches can be big); a slice is also checked against the oracle
+    rng = np.random.default_rng(20241003)
+    try:
+        for trial in range(40):
+            M = int(rng.integers(0, 9)); X = int(rng.integers(-12, min(M, 1))); E = int(rng.integers(-6, 1)); O = int(rng.integers(-14, 1))
+            prm = tsta_amd.Params(M, X, E, O)
+            pairs = []
+            for k in range(48):
+                n = int(rng.integers(1, 2600)); m = int(rng.integers(1, 2600))
+                a = util.random_dna(int(rng.integers(1 << 30)), n)
+                kind = k % 4
+                if kind == 0:
+                    b = _fixed_len(util.mutate(a, int(rng.integers(1 << 30)), 0.03 + 0.3 * rng.random()), m, k)
+                elif kind == 1:
+                    b = util.random_dna(int(rng.integers(1 << 30)), m)
+                elif kind == 2:
+                    b = util.low_complexity(int(rng.integers(1 << 30)), m, int(rng.integers(1, 5)))
+                else:
+                    b = _fixed_len(a, m, k)
+                pairs.append((a, b))
+            res = {}
+            for mode in (0, 16, 8):
+                eng.set_option("psa_packed", mode)
+                res[mode] = eng.psa_score_batch(pairs, prm)
+            assert np.array_equal(res[0], res[16]), (trial, M, X, E, O)
+            assert np.array_equal(res[0], res[8]), (trial, M, X, E, O)
+            if trial % 8 == 0:
+                assert np.array_equal(res[0], util.oracle_maxscore_batch(pairs, M=M, X=X, E=E, O=O)), (trial, M, X, E, O)
+    finally:
+        eng.set_option("psa_packed", -1)
