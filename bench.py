@@ -210,7 +210,12 @@ def main():
                          "kernel": "psa_score_packed_kernel", "kernel_ms": kern_ms,
                          "note": "integer max-plus recurrence: VALU-issue-bound, HBM fraction is ~0 by construction "
                                  "(SURVEY 8d); see valu_roofline"},
+            # data-sheet VALU peak (one wave64 instruction per 2 cycles per SIMD) and, next to it, the issue rate this
+            # dependent integer stream actually sustains on gfx950 (one per ~4 cycles per SIMD at 2.39 GHz, measured with
+            # tools/step_microbench.hip and in-kernel s_memtime stamps)
             "valu_roofline": {"ops_per_cell": VALU_OPS_PER_CELL,
+                              "measured_issue_ceiling": 256 * 4 * 64 * 2.39e9 / 4.0 / 1e12,
+                              "frac_of_measured_ceiling": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / (256 * 4 * 64 * 2.39e9 / 4.0),
                               "achieved": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / 1e12,
                               "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
                               "frac": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS},
