@@ -59,13 +59,13 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
                                       const unsigned pf)
 {
     s.cch = ushr1(s.ach, s.cch);
+    s.ach = ushl1(s.ach, s.ach);
     const unsigned hu = ushr1(s.th, s.hbot);
+    s.th = ushl1(s.th, s.th);
     unsigned eu = ushr1(s.te, s.ebot);
+    s.te = ushl1(s.te, s.te);
     s.sh = ushl1(s.hbot, s.sh);
     s.se = ushl1(s.ebot, s.se);
-    s.th = ushl1(s.th, s.th);
-    s.te = ushl1(s.te, s.te);
-    s.ach = ushl1(s.ach, s.ach);
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     unsigned d = s.hd;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
         if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
         if (t0 >= 64 && t0 + 63 < nmin) {
-#pragma unroll 1
+#pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
 #pragma unroll 1
