@@ -47,7 +47,7 @@ void tsta_engine_destroy(tsta_engine* eng);
 void tsta_free(void* p);                                   /* frees host buffers returned by this library */
 
 /* Tuning knobs (tests / experiments; results never depend on them).  Keys:
- *   "psa_packed"      -1 auto (default) | 0 never use the packed 16-bit kernel | 8 / 16 force it with that many rows per lane
+ *   "psa_packed"      -1 auto (default) | 0 never use the packed 16-bit kernel | 8 / 16 / 32 force it with that many rows per lane
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline

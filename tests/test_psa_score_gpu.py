@@ -133,7 +133,7 @@ def test_packed_couples_equal_geometry(eng, scoring):
             pairs.append((a, b) if j == 0 else (b, a))                                    # second member swapped
     want = util.oracle_maxscore_batch(pairs, **scoring)
     try:
-        for mode in (16, 8, 0):          # forced packed R=16 / R=8 (falls back when the scoring does not fit) / int32 only
+        for mode in (32, 16, 8, 0):      # forced packed R=32 / 16 / 8 (falls back when the scoring does not fit) / int32 only
             eng.set_option("psa_packed", mode)
             got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
             assert np.array_equal(got, want), (mode, scoring, got.tolist(), want.tolist())
@@ -152,7 +152,7 @@ def test_packed_adversarial_content(eng):
              (np.concatenate([x[:3000], A[:3000]]), np.concatenate([A[:3000], x[:3000]])),   # long forced gaps
              (x, np.concatenate([x[3000:], x[:3000]]))]
     try:
-        eng.set_option("psa_packed", 16)
+        eng.set_option("psa_packed", 32)
         # the last two sit just inside the 16-bit range bound of the packed kernel for R=16 and for R=8
         for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=3, X=-1, E=0, O=-7), dict(M=5, X=-4, E=-6, O=-8),
                    dict(M=10, X=-9, E=-10, O=-12)):
@@ -170,7 +170,7 @@ def test_packed_and_int32_paths_agree_at_50k(eng, monkeypatch):
     z = _fixed_len(util.mutate(x, 4244, 0.15), 50_000, 2)
     want = [util.oracle_maxscore(x, y), util.oracle_maxscore(x, z)]
     try:
-        for mode in (16, 0):
+        for mode in (32, 16, 0):
             eng.set_option("psa_packed", mode)
             got = eng.psa_score_batch([(x, y), (x, z)])
             assert got.tolist() == want, mode
@@ -218,7 +218,7 @@ def test_packed_couples_of_unequal_size(eng, scoring):
             pairs.append((a, b) if (i % 3) else (b, a))
     want = util.oracle_maxscore_batch(pairs, **scoring)
     try:
-        for mode in (16, 8):
+        for mode in (32, 16, 8):
             eng.set_option("psa_packed", mode)
             got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
             assert np.array_equal(got, want), (mode, scoring, got.tolist(), want.tolist())
@@ -315,9 +315,10 @@ def test_fuzz_packed_vs_int32_vs_oracle(eng):
                     b = _fixed_len(a, m, k)
                 pairs.append((a, b))
             res = {}
-            for mode in (0, 16, 8):
+            for mode in (0, 32, 16, 8):
                 eng.set_option("psa_packed", mode)
                 res[mode] = eng.psa_score_batch(pairs, prm)
+            assert np.array_equal(res[0], res[32]), (trial, M, X, E, O)
             assert np.array_equal(res[0], res[16]), (trial, M, X, E, O)
             assert np.array_equal(res[0], res[8]), (trial, M, X, E, O)
             if trial % 8 == 0:

@@ -150,7 +150,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!eng || !key) return TSTA_ERR_INVALID_ARG;
     Engine* e = reinterpret_cast<Engine*>(eng);
     const int v = (int)value;
-    if (!strcmp(key, "psa_packed") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_packed = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_packed") && (v == -1 || v == 0 || v == 8 || v == 16 || v == 32)) { e->opt_psa_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
     if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }

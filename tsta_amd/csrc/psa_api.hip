@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "../../include/tsta_engine.h"
@@ -27,17 +28,26 @@ static int psa_rows_per_lane(int32_t max_len, int forced)
 // does not fit: the kernel needs E,O <= 0 <= M, 0 <= M-X <= 255 and every value in flight within the 16-bit
 // window around the per-pair base: (64R+256)*U + |O+E| + |O| + 200*M < 28000, U = max(M,X,0)+|O|+|E| bounding the
 // score difference of adjacent cells.
-static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int mode)   // mode: -1 auto, 0 never, 8/16 forced
+static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int mode, int32_t max_len)   // mode: -1 auto, 0 never, 8/16/32 forced
 {
     if (mode == 0 || couples < 1) return 0;
     if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
     if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
     const int64_t U = std::max(std::max(p.M, p.X), 0) - (int64_t)p.O - (int64_t)p.E;
     auto fits = [&](int R) { return (64LL * R + 256) * U - 2LL * p.O - p.E + 200LL * p.M < 28000; };   // rows 64R + columns <= 192 (drain block) from the anchor; +M per column of the shifted frame
-    if (mode == 8) return fits(8) ? 8 : 0;
+    if (mode == 32) return fits(32) ? 32 : (fits(16) ? 16 : (fits(8) ? 8 : 0));
     if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
-    if (fits(16)) return 16;
-    return fits(8) ? 8 : 0;
+    if (mode == 8) return fits(8) ? 8 : 0;
+    // auto: the band height 64R that costs least for sequences of this length: padded rows x instructions per cell
+    // (5.5 per cell + ~19 per step of 2R cells for the lane hand-off); taller bands also halve the boundary-row traffic
+    int best = 0; double best_cost = 0;
+    for (int R : {32, 16, 8}) {
+        if (!fits(R)) continue;
+        const double band = 64.0 * R;
+        const double cost = std::ceil(std::max(1, (int)max_len) / band) * band * (5.5 + 9.5 / R);
+        if (!best || cost < best_cost) { best = R; best_cost = cost; }
+    }
+    return best;
 }
 
 // geometry key of a pair: (columns n = longer sequence) << 32 | (rows m = shorter)
@@ -93,7 +103,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     // one wave nearly saturates a SIMD, so packing two pairs per wave only pays once there are more
     // pairs than SIMDs; below that the int32 kernel keeps every SIMD busy with one pair each
     const bool enough = n_pairs > (int64_t)e->n_cu * 4 || e->opt_psa_packed > 0;
-    const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2, e->opt_psa_packed) : 0;
+    const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2, e->opt_psa_packed, max_len) : 0;
     const int64_t couples = Rp ? n_pairs / 2 : 0;
     int64_t pblocks = 0;
     if (couples) {

@@ -269,15 +269,17 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
 
 void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream)
 {
-    if (R == 8) hipLaunchKernelGGL((psa_score_packed_kernel<8, 4>), dim3(blocks), dim3(256), 0, stream, args);
-    else        hipLaunchKernelGGL((psa_score_packed_kernel<16, 4>), dim3(blocks), dim3(256), 0, stream, args);
+    if (R == 8)       hipLaunchKernelGGL((psa_score_packed_kernel<8, 4>), dim3(blocks), dim3(256), 0, stream, args);
+    else if (R == 32) hipLaunchKernelGGL((psa_score_packed_kernel<32, 2>), dim3(blocks), dim3(256), 0, stream, args);
+    else              hipLaunchKernelGGL((psa_score_packed_kernel<16, 3>), dim3(blocks), dim3(256), 0, stream, args);
 }
 
 int psa_packed_blocks_per_cu(int R)
 {
     int nb = 0;
-    hipError_t e = (R == 8) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<8, 4>, 256, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<16, 4>, 256, 0);
+    hipError_t e = (R == 8)  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<8, 4>, 256, 0)
+                 : (R == 32) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<32, 2>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<16, 3>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb > 8 ? 8 : nb;
 }
