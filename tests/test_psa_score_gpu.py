@@ -141,6 +141,36 @@ def test_packed_couples_equal_geometry(eng, scoring):
         eng.set_option("psa_packed", -1)
 
 
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=3, X=-1, E=0, O=-7),
+                                     dict(M=4, X=-6, E=-3, O=-5), dict(M=2, X=-5, E=-9, O=-1)])
+def test_packed_max_elision(eng, scoring):
+    # Blocks whose entering scores prove that maxsorce cannot rise there run without the running max, in a row-shifted
+    # frame (psa_score_packed.hip: pstep_elided).  The decision is data dependent: cover maxima reached early, late,
+    # in the middle, never (floor -100), and pairs hovering around the bound; with and without the elision.
+    n = 7000
+    x = util.random_dna(61, n); y = util.random_dna(62, n); z = util.random_dna(63, n)
+    A = np.full(n, ord("A"), np.uint8)
+    pairs = [(x, y), (x, x.copy()), (y, util.mutate(y, 64, 0.03)[:n]),
+             (np.concatenate([x[:1500], y[1500:]]), np.concatenate([x[:1500], z[1500:]])),       # maximum early, then decay
+             (np.concatenate([y[:4500], x[4500:]]), np.concatenate([z[:4500], x[4500:]])),       # climbs back late
+             (np.concatenate([y[:2500], x[2500:4500], y[4500:]]), np.concatenate([z[:2500], x[2500:4500], z[4500:]])),
+             (np.concatenate([x[:3000], A[:3000]]), np.concatenate([A[:3000], x[:3000]])),       # long forced gaps
+             (x, np.concatenate([x[3500:], x[:3500]])),                                           # off-diagonal identity
+             (x[:6000], util.mutate(x, 65, 0.25)[:4200]), (z, util.mutate(z, 66, 0.12)[:n]),
+             (util.low_complexity(67, n, 2), util.low_complexity(68, n, 2)), (A, A.copy())]
+    want = util.oracle_maxscore_batch(pairs, **scoring)
+    try:
+        for mode in (32, 16, 8):
+            for elide in (1, 0):
+                eng.set_option("psa_packed", mode)
+                eng.set_option("psa_elide", elide)
+                got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+                assert np.array_equal(got, want), (mode, elide, scoring, got.tolist(), want.tolist())
+    finally:
+        eng.set_option("psa_packed", -1)
+        eng.set_option("psa_elide", 1)
+
+
 def test_packed_adversarial_content(eng):
     n = 6000
     A = np.full(n, ord("A"), np.uint8); C = np.full(n, ord("C"), np.uint8)

@@ -88,6 +88,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (!e) return TSTA_ERR_OOM;
     e->device = device;
     if (const char* v = getenv("TSTA_PSA_PACKED")) e->opt_psa_packed = atoi(v);
+    if (const char* v = getenv("TSTA_PSA_ELIDE")) e->opt_psa_elide = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
@@ -104,20 +105,26 @@ int tsta_engine_create(int device, tsta_engine** out)
     if ((rc = e->check(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate")) != TSTA_OK ||
         (rc = e->check(hipEventCreate(&e->ev0), "hipEventCreate")) != TSTA_OK ||
         (rc = e->check(hipEventCreate(&e->ev1), "hipEventCreate")) != TSTA_OK ||
-        (rc = e->reserve(e->counter, 256, "hipMalloc(counter)")) != TSTA_OK) {
+        (rc = e->reserve(e->counter, 4096, "hipMalloc(counter)")) != TSTA_OK) {
         tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e)); return rc;
     }
     // hardware contract check: DPP whole-wave shifts behave as wave_ops.h assumes
     int* d = reinterpret_cast<int*>(e->counter.p);
     tsta::launch_dpp_selftest(d, e->stream);
-    int h[128];
+    int h[640];
     if ((rc = e->check(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, e->stream), "selftest copy")) != TSTA_OK ||
         (rc = e->check(hipStreamSynchronize(e->stream), "selftest sync")) != TSTA_OK) {
         tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e)); return rc;
     }
     for (int l = 0; l < 64; ++l) {
         const int ea = l == 0 ? 1000 : l - 1, eb = l == 63 ? 2063 : l + 1;
-        if (h[l] != ea || h[64 + l] != eb) {
+        // lane_exchange: cch/hu/eu shift down with injection at lane 0, sh/se shift up with injection at lane 63,
+        // ach/th/te rotate up (lane 63 keeps its own value)
+        const int x_cch = l == 0 ? 400 : 100 + l - 1, x_hu = l == 0 ? 500 : 700 + l - 1, x_eu = l == 0 ? 600 : 800 + l - 1;
+        const int x_sh = l == 63 ? 763 : 200 + l + 1, x_se = l == 63 ? 863 : 300 + l + 1;
+        const int x_ach = l == 63 ? 463 : 400 + l + 1, x_th = l == 63 ? 563 : 500 + l + 1, x_te = l == 63 ? 663 : 600 + l + 1;
+        if (h[l] != ea || h[64 + l] != eb || h[128 + l] != x_cch || h[192 + l] != x_hu || h[256 + l] != x_eu ||
+            h[320 + l] != x_sh || h[384 + l] != x_se || h[448 + l] != x_ach || h[512 + l] != x_th || h[576 + l] != x_te) {
             e->set_error("DPP wave shift self-test failed at lane %d", l);
             tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e));
             return TSTA_ERR_INTERNAL;
@@ -153,6 +160,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_packed") && (v == -1 || v == 0 || v == 8 || v == 16 || v == 32)) { e->opt_psa_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
     if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_elide") && (v == 0 || v == 1)) { e->opt_psa_elide = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;

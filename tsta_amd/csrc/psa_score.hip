@@ -189,6 +189,13 @@ __global__ void dpp_selftest_kernel(int* out)
     const int b = wave_shl1(2000 + lane, lane);     // lane63 -> 2063, lane l -> l+1
     out[lane] = a;
     out[64 + lane] = b;
+    // lane_exchange (v_cndmask_b32_dpp with bound_ctrl) as the packed kernel uses it
+    unsigned cch = 100 + lane, hu, eu, sh = 200 + lane, se = 300 + lane, ach = 400 + lane, th = 500 + lane, te = 600 + lane;
+    const unsigned hbot = 700 + lane, ebot = 800 + lane;
+    asm volatile("s_nop 1");
+    lane_exchange(cch, hu, eu, sh, se, ach, th, te, hbot, ebot);
+    out[128 + lane] = cch; out[192 + lane] = hu; out[256 + lane] = eu; out[320 + lane] = sh;
+    out[384 + lane] = se; out[448 + lane] = ach; out[512 + lane] = th; out[576 + lane] = te;
 }
 
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream)

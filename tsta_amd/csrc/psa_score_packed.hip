@@ -31,6 +31,9 @@ __device__ __forceinline__ unsigned pkmin(unsigned a, unsigned b) {
 __device__ __forceinline__ unsigned pksub(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
 }
+__device__ __forceinline__ unsigned pkadd(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
 __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 __device__ __forceinline__ unsigned ushr1(unsigned old, unsigned src) { return (unsigned)wave_shr1((int)old, (int)src); }
 __device__ __forceinline__ unsigned ushl1(unsigned old, unsigned src) { return (unsigned)wave_shl1((int)old, (int)src); }
@@ -58,14 +61,8 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
                                       const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
                                       const unsigned pf)
 {
-    s.cch = ushr1(s.ach, s.cch);
-    s.ach = ushl1(s.ach, s.ach);
-    const unsigned hu = ushr1(s.th, s.hbot);
-    s.th = ushl1(s.th, s.th);
-    unsigned eu = ushr1(s.te, s.ebot);
-    s.te = ushl1(s.te, s.te);
-    s.sh = ushl1(s.hbot, s.sh);
-    s.se = ushl1(s.ebot, s.se);
+    unsigned hu, eu;
+    lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     unsigned d = s.hd;
@@ -109,6 +106,59 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
     s.joff += pm;
 }
 
+// ---- steady-state step without the running max ("elided" blocks) -------------------------------------------------
+// In the H' frame every transition is <= 0 (diagonal 0 / X-M, vertical -|E|, horizontal -|E|-M, opening O <= 0), so no
+// cell of a 64-step block exceeds the largest H' that ENTERS the block (the lanes' previous-column H', the diagonal
+// entries and the 64 top-row entries), and  H = H' + (column+1)*M  <=  that maximum + (t0+64)*M.  When this bound is
+// <= the maximum the pair has ALREADY reached, the block cannot change maxsorce: every cell is still computed (the
+// bands below need the boundary row), but nothing has to be compared against the running max, and with no maximum to
+// keep the rows need not share a frame either.  Such a block runs in the frame
+//     H*(i,c) = H'(i,c) + |E|*(i - top row of the band) - |E|*(c - (t0-1))  (- a per-band constant, for the u16 range)
+// in which the VERTICAL gap costs nothing (E* = Ebar*(up)), the diagonal still costs 0 / X-M and the horizontal gap
+// 2|E|+M:  8 + 1 VALU per cell pair instead of 11.  State is converted on entry and exit (2R+5 packed adds each, per
+// 64 steps), so blocks of either kind can follow each other freely and results are identical by construction.
+template <int R>
+__device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, const unsigned pmx, const unsigned pf2)
+{
+    unsigned hu, eu;
+    lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+    unsigned d = s.hd;
+    unsigned h = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned f = s.fb[k] - pf2;                // F* = Fbar*(left) - (2|E|+M)
+        const unsigned x = s.cch ^ s.bch[k];
+        const unsigned tt = pkmin(x, pmx);
+        const unsigned dg = d - tt;
+        h = pkmax(pkmax(dg, eu), f);                     // E* = Ebar*(up): no subtraction
+        const unsigned g = h - po;
+        d = s.hl[k];
+        s.hl[k] = h;
+        s.fb[k] = pkmax(f, g);
+        eu = pkmax(eu, g);
+    }
+    s.hbot = h;
+    s.ebot = eu;
+    s.hd = hu;
+}
+
+// frame change H' -> H* (sign = +1) or back (sign = -1) of everything a lane carries across a block boundary;
+// `after` = 0 at the block's first step, 64 after its last one (the lane has moved 64 columns to the right).
+template <int R>
+__device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const int ae, const int sign, const int after)
+{
+    const int lane_part = (ln - 32) * (R + 1) - after;             // rows above this lane + its column lead, centred
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int v = sign * ae * (lane_part + k + 1);
+        const unsigned pv = pack2(v, v);
+        s.hl[k] = pkadd(s.hl[k], pv);
+        s.fb[k] = pkadd(s.fb[k], pv);
+    }
+    { const int v = sign * ae * lane_part;       const unsigned pv = pack2(v, v); s.hd = pkadd(s.hd, pv); }
+    { const int v = sign * ae * (lane_part + R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
+}
+
 __device__ __forceinline__ int hcol0p(int i, int E, int O) { return i == 0 ? 0 : O + i * E; }
 
 struct PairAcc { int baseA, baseB, mxA, mxB, ancA, ancB; };   // base: anchor of the H' frame; anc: anchor of the running max (H frame)
@@ -133,10 +183,12 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
                                       const bool store_bottom,
                                       const int band_row0, int2* __restrict__ rowA, int2* __restrict__ rowB,
                                       PairAcc& acc, const int lane, const int M, const int E, const int O,
-                                      const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s)
+                                      const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
+                                      const bool elide_ok)
 {
     const unsigned pe = in_vgpr(pe_s), po = in_vgpr(po_s), pm = in_vgpr(pm_s), pmx = in_vgpr(pmx_s);
     const unsigned pf = pe + pm;                   // |E| + M: the horizontal gap pays the column shift of the H' frame
+    const unsigned pf2 = pf + pe;                  // 2|E| + M: the same in the frame of the elided blocks
     PLane<R> s;
     const int n = max(nA, nB), nmin = min(nA, nB);
     const int i0 = band_row0 + lane * R;
@@ -192,7 +244,27 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         const int cn = t0 + 64 + ln;
         if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
         if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
-        if (t0 >= 64 && t0 + 63 < nmin) {
+        const bool steady = t0 >= 64 && t0 + 63 < nmin;
+        bool elide = false;
+        if (!PARTIAL && steady && elide_ok) {
+            // can this block raise either pair's maximum?  (see pstep_elided)
+            unsigned v = pkmax(s.hd, s.th);
+#pragma unroll
+            for (int k = 0; k < R; ++k) v = pkmax(v, s.hl[k]);
+            const int ubA = wave_max((int)(v & 0xffffu)) - kBias + acc.baseA + (t0 + 64) * M;
+            const int ubB = wave_max((int)(v >> 16)) - kBias + acc.baseB + (t0 + 64) * M;
+            elide = ubA <= max(wave_max(acc.mxA), -100) && ubB <= max(wave_max(acc.mxB), -100);
+        }
+        if (elide) {
+            const int ae = -E;
+            elided_frame<R>(s, ln, ae, +1, 0);
+            { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+#pragma unroll 2
+            for (int q = 0; q < 64; ++q) pstep_elided<R>(s, po, pmx, pf2);
+            elided_frame<R>(s, ln, ae, -1, 64);
+            // the 64 captured bottom-row entries (column t0-64+lane): row 64R below the top, 63-lane columns behind t0-1
+            { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
+        } else if (steady) {
 #pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
@@ -213,7 +285,8 @@ template <int R>
 __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
                                               int nA, int mA, int nB, int mB, int2* rowA, int2* rowB, int lane,
                                               int M, int E, int O,
-                                              unsigned pe, unsigned po, unsigned pm, unsigned pmx, int& outA, int& outB)
+                                              unsigned pe, unsigned po, unsigned pm, unsigned pmx, bool elide_ok,
+                                              int& outA, int& outB)
 {
     const int n = max(nA, nB), mmax = max(mA, mB), mmin = min(mA, mB);
     for (int c = opaque(lane); c < n; c += 64) {          // blockmatrix_init, psa.c:221-226
@@ -226,8 +299,8 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     constexpr int BAND = 64 * R;
     for (int r0 = 0; r0 < mmax; r0 += BAND) {
         const bool last = r0 + BAND >= mmax;
-        if (r0 + BAND <= mmin) pband<R, false>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
-        else                   pband<R, true>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx);
+        if (r0 + BAND <= mmin) pband<R, false>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        else                   pband<R, true>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
         if (!last) wave_mem_sync();
     }
     outA = wave_max(acc.mxA);
@@ -260,7 +333,7 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         const int nA = swa ? l2a : l1a, mA = swa ? l1a : l2a;
         const int nB = swb ? l2b : l1b, mB = swb ? l1b : l2b;
         int ra, rb;
-        pscore_couple<R>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, ra, rb);
+        pscore_couple<R>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
         wave_mem_sync();
     }

@@ -20,6 +20,40 @@ __device__ __forceinline__ int wave_shl1(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
 }
 
+// The whole per-step lane hand-off of the skewed DP sweep in ONE asm block (8 VALU + 3 SALU issue slots):
+//   cch  <- lane l-1's cch            (lane 0  <- ach[0])      column character moves down one lane
+//   hu   <- lane l-1's hbot           (lane 0  <- th[0])       H of the row above
+//   eu   <- lane l-1's ebot           (lane 0  <- te[0])       Ebar of the row above
+//   sh   <- lane l+1's sh             (lane 63 <- hbot[63])    bottom-row capture (shift register)
+//   se   <- lane l+1's se             (lane 63 <- ebot[63])
+//   ach, th, te rotate left by one lane (next column's character / top-row entry into lane 0)
+// `v_cndmask_b32_dpp d, shifted, inject, vcc ... bound_ctrl:0` selects the injected value in the ONE lane named by VCC
+// and the DPP-shifted value elsewhere, so no register copy for an `old` operand and none of the s_nop pairs the
+// compiler puts between such a copy and its v_mov_dpp.  Hazards inside the block: every DPP source was written at least
+// two instructions earlier (hbot/ebot by the caller's last step, then >= 3 instructions of this block come first).
+__device__ __forceinline__ void lane_exchange(unsigned& cch, unsigned& hu, unsigned& eu, unsigned& sh, unsigned& se,
+                                              unsigned& ach, unsigned& th, unsigned& te, unsigned hbot, unsigned ebot)
+{
+    // hu / eu are produced IN PLACE in the registers holding hbot / ebot (their last readers come first)
+    hu = hbot;
+    eu = ebot;
+    asm volatile(
+        "s_mov_b64 vcc, 1\n\t"
+        "v_cndmask_b32_dpp %0, %0, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_lshl_b64 vcc, 1, 63\n\t"
+        "v_cndmask_b32_dpp %3, %3, %1, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cndmask_b32_dpp %4, %4, %2, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_mov_b64 vcc, 1\n\t"
+        "v_cndmask_b32_dpp %1, %1, %6, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %2, %7, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(cch), "+v"(hu), "+v"(eu), "+v"(sh), "+v"(se), "+v"(ach), "+v"(th), "+v"(te)
+        :
+        : "vcc", "scc");
+}
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
