@@ -50,6 +50,7 @@ void tsta_free(void* p);                                   /* frees host buffers
  *   "psa_packed"      -1 auto (default) | 0 never use the packed 16-bit kernel | 8 / 16 / 32 force it with that many rows per lane
  *   "psa_elide"        1 (default) | 0: packed kernel keeps the running max in every block, also where a bound shows
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
+ *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline

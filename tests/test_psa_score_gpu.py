@@ -158,17 +158,23 @@ def test_packed_max_elision(eng, scoring):
              (x, np.concatenate([x[3500:], x[:3500]])),                                           # off-diagonal identity
              (x[:6000], util.mutate(x, 65, 0.25)[:4200]), (z, util.mutate(z, 66, 0.12)[:n]),
              (util.low_complexity(67, n, 2), util.low_complexity(68, n, 2)), (A, A.copy())]
+    # pure-ACGT couples take the byte-permute mismatch lookup; a single other byte (here: n / lower case) sends the
+    # couple down the generic compare, and the reference compares bytes case-sensitively (psa.c:253)
+    xn = x.copy(); xn[5000] = ord("N"); yl = y.copy(); yl[10:20] += 32
+    pairs += [(xn, x.copy()), (x, yl), (xn, xn.copy()), (yl, util.mutate(y, 69, 0.05)[:n])]
     want = util.oracle_maxscore_batch(pairs, **scoring)
     try:
         for mode in (32, 16, 8):
-            for elide in (1, 0):
+            for elide, perm in ((1, 1), (0, 1), (1, 0), (0, 0)):
                 eng.set_option("psa_packed", mode)
                 eng.set_option("psa_elide", elide)
+                eng.set_option("psa_perm", perm)
                 got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
-                assert np.array_equal(got, want), (mode, elide, scoring, got.tolist(), want.tolist())
+                assert np.array_equal(got, want), (mode, elide, perm, scoring, got.tolist(), want.tolist())
     finally:
         eng.set_option("psa_packed", -1)
         eng.set_option("psa_elide", 1)
+        eng.set_option("psa_perm", 1)
 
 
 def test_packed_adversarial_content(eng):

@@ -89,6 +89,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     e->device = device;
     if (const char* v = getenv("TSTA_PSA_PACKED")) e->opt_psa_packed = atoi(v);
     if (const char* v = getenv("TSTA_PSA_ELIDE")) e->opt_psa_elide = atoi(v) != 0;
+    if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
@@ -111,7 +112,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     // hardware contract check: DPP whole-wave shifts behave as wave_ops.h assumes
     int* d = reinterpret_cast<int*>(e->counter.p);
     tsta::launch_dpp_selftest(d, e->stream);
-    int h[640];
+    int h[704];
     if ((rc = e->check(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, e->stream), "selftest copy")) != TSTA_OK ||
         (rc = e->check(hipStreamSynchronize(e->stream), "selftest sync")) != TSTA_OK) {
         tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e)); return rc;
@@ -124,7 +125,7 @@ int tsta_engine_create(int device, tsta_engine** out)
         const int x_sh = l == 63 ? 763 : 200 + l + 1, x_se = l == 63 ? 863 : 300 + l + 1;
         const int x_ach = l == 63 ? 463 : 400 + l + 1, x_th = l == 63 ? 563 : 500 + l + 1, x_te = l == 63 ? 663 : 600 + l + 1;
         if (h[l] != ea || h[64 + l] != eb || h[128 + l] != x_cch || h[192 + l] != x_hu || h[256 + l] != x_eu ||
-            h[320 + l] != x_sh || h[384 + l] != x_se || h[448 + l] != x_ach || h[512 + l] != x_th || h[576 + l] != x_te) {
+            h[640 + l] != (int)(0x00330000u | ((0x88776655u + (unsigned)l) >> 8 & 0xffu)) || h[320 + l] != x_sh || h[384 + l] != x_se || h[448 + l] != x_ach || h[512 + l] != x_th || h[576 + l] != x_te) {
             e->set_error("DPP wave shift self-test failed at lane %d", l);
             tsta_engine_destroy(reinterpret_cast<tsta_engine*>(e));
             return TSTA_ERR_INTERNAL;
@@ -141,7 +142,7 @@ void tsta_engine_destroy(tsta_engine* eng)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
-                            &e->scratch2}) {
+                            &e->scratch2, &e->pair_flags}) {
         if (b->p) (void)hipFree(b->p);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -161,6 +162,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
     if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
     if (!strcmp(key, "psa_elide") && (v == 0 || v == 1)) { e->opt_psa_elide = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;

@@ -42,6 +42,7 @@ __host__ __device__ inline bool psa_couple_is_packed(const int32_t* len1, const 
 struct PsaPackedArgs {
     PsaBatchArgs b;                 // same batch description; b.counter -> this kernel's own ticket word
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
+    const uint8_t* acgt;            // per pair: 1 iff both sequences consist of the bytes A, C, G, T only (may be null)
     int32_t  elide;                 // 1: blocks that provably cannot raise the maximum run without the running max
 };
 

@@ -55,6 +55,41 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int m
     return best;
 }
 
+// flags[k] = 1 iff both sequences of pair k consist of the bytes 'A', 'C', 'G', 'T' only: such pairs take the
+// byte-permute form of the mismatch term in the packed kernel (psa_score_packed.hip: mismatch_term).  One block per
+// pair (grid-stride); reads every sequence byte once, ~0.1 % of the fill's time.
+__global__ __launch_bounds__(256) void psa_alphabet_flags_kernel(const uint8_t* __restrict__ seqs, const int64_t* off1, const int32_t* len1,
+                                                                 const int64_t* off2, const int32_t* len2, int64_t n_pairs, uint8_t* flags)
+{
+    __shared__ int bad;
+    for (int64_t k = blockIdx.x; k < n_pairs; k += gridDim.x) {
+        if (threadIdx.x == 0) bad = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int which = 0; which < 2; ++which) {
+            const uint8_t* p = seqs + (which ? off2[k] : off1[k]);
+            const int64_t n = which ? len2[k] : len1[k];
+            // head up to 4-byte alignment, aligned words, tail
+            const int64_t head = min<int64_t>(n, (int64_t)((4 - ((uintptr_t)p & 3)) & 3));
+            for (int64_t i = threadIdx.x; i < head; i += blockDim.x) { const uint8_t c = p[i]; mine |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(p + head);
+            const int64_t nw = (n - head) / 4;
+            for (int64_t i = threadIdx.x; i < nw; i += blockDim.x) {
+                const uint32_t x = w[i];
+                // per byte: x == 'A' (0x41) | 'C' (0x43) | 'G' (0x47) | 'T' (0x54)
+                uint32_t ok = 0;
+                for (int b = 0; b < 4; ++b) { const uint32_t c = (x >> (8 * b)) & 0xffu; ok += (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+                mine |= ok != 4;
+            }
+            for (int64_t i = head + nw * 4 + threadIdx.x; i < n; i += blockDim.x) { const uint8_t c = p[i]; mine |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+        }
+        if (mine) bad = 1;
+        __syncthreads();
+        if (threadIdx.x == 0) flags[k] = bad ? 0 : 1;
+        __syncthreads();
+    }
+}
+
 // geometry key of a pair: (columns n = longer sequence) << 32 | (rows m = shorter)
 __global__ void psa_geometry_keys_kernel(const int32_t* len1, const int32_t* len2, int64_t n_pairs, uint64_t* keys, uint32_t* idx)
 {
@@ -136,6 +171,10 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     a.clock_out = want_clock ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->counter.p) + 64) : nullptr;
 
     if ((rc = e->check(hipMemsetAsync(a.counter, 0, 2 * sizeof(unsigned int), s), "hipMemsetAsync")) != TSTA_OK) return rc;
+    const uint8_t* acgt = nullptr;
+    if (couples && e->opt_psa_perm != 0 && p->M - p->X <= 255 &&
+        e->reserve(e->pair_flags, (size_t)n_pairs, "hipMalloc(alphabet flags)") == TSTA_OK)
+        acgt = reinterpret_cast<const uint8_t*>(e->pair_flags.p);
     e->timing_begin(s);
     int launches = 0;
     if (couples) {
@@ -150,6 +189,12 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         pa.pe = ae | (ae << 16); pa.po = ao | (ao << 16); pa.pm = am | (am << 16); pa.pmx = amx | (amx << 16);
         // the frame of the elided blocks spreads the rows of a band by |E| each: needs that much more of the 16-bit window
         pa.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(*p, Rp) + (int64_t)ae * (32 * (Rp + 1) + 192) < 28000;
+        pa.acgt = acgt;
+        if (acgt) {
+            hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,
+                               d_seqs, d_off1, d_len1, d_off2, d_len2, n_pairs, reinterpret_cast<uint8_t*>(e->pair_flags.p));
+            ++launches;
+        }
         tsta::launch_psa_score_packed(Rp, pa, (int)pblocks, s);
         ++launches;
     }

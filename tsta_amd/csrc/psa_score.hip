@@ -196,6 +196,8 @@ __global__ void dpp_selftest_kernel(int* out)
     lane_exchange(cch, hu, eu, sh, se, ach, th, te, hbot, ebot);
     out[128 + lane] = cch; out[192 + lane] = hu; out[256 + lane] = eu; out[320 + lane] = sh;
     out[384 + lane] = se; out[448 + lane] = ach; out[512 + lane] = th; out[576 + lane] = te;
+    // v_perm_b32 byte selectors as the packed kernel's mismatch lookup assumes: 0-3 second operand, 4-7 first, 0x0c -> 0
+    out[640 + lane] = (int)__builtin_amdgcn_perm(0x44332211u, 0x88776655u + (unsigned)lane, 0x0c060c01u);
 }
 
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream)

@@ -38,6 +38,22 @@ __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo
 __device__ __forceinline__ unsigned ushr1(unsigned old, unsigned src) { return (unsigned)wave_shr1((int)old, (int)src); }
 __device__ __forceinline__ unsigned ushl1(unsigned old, unsigned src) { return (unsigned)wave_shl1((int)old, (int)src); }
 
+// 0 / M-X per half for (column character, row character):
+//   generic bytes:  min_u16((a ^ b) << 8, M-X)                                              (2 VALU)
+//   PERM couples (both pairs pure ACGT): one v_perm_b32 byte lookup.  The column carries, per pair, a 4-byte table
+//   indexed by the ROW's 2-bit code ((c >> 1) & 3: A 0, C 1, T 2, G 3) holding 0 at the column's own code and M-X
+//   elsewhere; the row register is the byte selector {codeA, 0x0c (-> 0x00), 4 + codeB, 0x0c}: selectors 0-3 read
+//   the second table operand (pair A), 4-7 the first (pair B).
+template <bool PERM>
+__device__ __forceinline__ unsigned mismatch_term(unsigned cch, unsigned cch2, unsigned bch, unsigned pmx)
+{
+    if (PERM) return __builtin_amdgcn_perm(cch2, cch, bch);
+    return pkmin(cch ^ bch, pmx);
+}
+__device__ __forceinline__ unsigned acgt_code(int c) { return ((unsigned)c >> 1) & 3u; }
+// the column's table for one pair: M-X in the four bytes, 0 at the column's own code
+__device__ __forceinline__ unsigned acgt_table(int c, unsigned k4) { return k4 & ~(0xffu << (8 * acgt_code(c))); }
+
 constexpr int kBias = 0x8000;
 constexpr int kNegInfP = -(1 << 30);
 
@@ -48,6 +64,7 @@ struct PLane {
     unsigned bch[R];   // row characters << 8 in each half
     unsigned hd;       // H'(row above first row, previous column)
     unsigned hbot, ebot, cch, th, te, ach, sh, se, mx;
+    unsigned cch2, ach2;   // PERM couples: the column character travels as two byte tables (pair A in cch/ach, pair B here)
     unsigned joff;     // (column of this step - (t0 - 63)) * M in both halves: turns H' back into H for the running max
 };
 
@@ -55,14 +72,15 @@ struct PLane {
 // diagonal term then needs no "+M":  D' = H'(i-1,j-1) - (match ? 0 : M-X);  the vertical gap is unchanged
 // (E' = Ebar'(i-1,j) - |E|, same column) and the horizontal gap pays the shift:  F' = Fbar'(i,j-1) - (|E|+M).
 // That removes one add per cell; the price is one add + one max per STEP to feed the running max in the H frame.
-template <int R, bool PRED, bool PARTIAL>
+template <int R, bool PRED, bool PARTIAL, bool PERM>
 __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
                                       const int nvA, const int nvB,
                                       const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
                                       const unsigned pf)
 {
     unsigned hu, eu;
-    lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+    if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
+    else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     unsigned d = s.hd;
@@ -72,8 +90,7 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
     for (int k = 0; k < R; ++k) {
         const unsigned e = eu - pe;                      // E' = Ebar'(up) - |E|        (v_sub_u32 on both halves)
         const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)
-        const unsigned x = s.cch ^ s.bch[k];             // 0 iff characters equal, else >= 256 per half
-        const unsigned tt = pkmin(x, pmx);               // 0 or M-X
+        const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);   // 0 or M-X
         const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
         h = pkmax(pkmax(dg, e), f);
         const unsigned g = h - po;                       // H' + O
@@ -117,18 +134,18 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
 // in which the VERTICAL gap costs nothing (E* = Ebar*(up)), the diagonal still costs 0 / X-M and the horizontal gap
 // 2|E|+M:  8 + 1 VALU per cell pair instead of 11.  State is converted on entry and exit (2R+5 packed adds each, per
 // 64 steps), so blocks of either kind can follow each other freely and results are identical by construction.
-template <int R>
+template <int R, bool PERM>
 __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, const unsigned pmx, const unsigned pf2)
 {
     unsigned hu, eu;
-    lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+    if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
+    else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
     unsigned d = s.hd;
     unsigned h = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const unsigned f = s.fb[k] - pf2;                // F* = Fbar*(left) - (2|E|+M)
-        const unsigned x = s.cch ^ s.bch[k];
-        const unsigned tt = pkmin(x, pmx);
+        const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);
         const unsigned dg = d - tt;
         h = pkmax(pkmax(dg, eu), f);                     // E* = Ebar*(up): no subtraction
         const unsigned g = h - po;
@@ -177,7 +194,7 @@ __device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("v_mov_b3
 
 // The two pairs of a couple may differ in size: the wave sweeps max(nA,nB) columns and max(mA,mB) rows; cells
 // outside the smaller pair compute garbage that only feeds other such cells and is masked out of its running max.
-template <int R, bool PARTIAL>
+template <int R, bool PARTIAL, bool PERM>
 __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int nA, const int nB,
                                       const uint8_t* __restrict__ bA, const uint8_t* __restrict__ bB, const int mA, const int mB,
                                       const bool store_bottom,
@@ -204,15 +221,23 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         const int hk = hcol0p(i0 + 1 + k, E, O);   // column 0: H' = H
         s.hl[k] = pack2(hk - acc.baseA + kBias, hk - acc.baseB + kBias);
         s.fb[k] = pack2(hk + O - acc.baseA + kBias, hk + O - acc.baseB + kBias);
-        const int cA = (i0 + k < mA) ? ((int)bA[i0 + k] << 8) : 0x1ff;
-        const int cB = (i0 + k < mB) ? ((int)bB[i0 + k] << 8) : 0x1ff;
-        s.bch[k] = pack2(cA, cB);
+        if (PERM) {                                 // byte selector {codeA, ->0, 4 + codeB, ->0}; rows beyond m select 0
+            const unsigned cA = (i0 + k < mA) ? acgt_code(bA[i0 + k]) : 0x0cu;
+            const unsigned cB = (i0 + k < mB) ? 4u + acgt_code(bB[i0 + k]) : 0x0cu;
+            s.bch[k] = cA | 0x0c00u | (cB << 16) | 0x0c000000u;
+        } else {
+            const int cA = (i0 + k < mA) ? ((int)bA[i0 + k] << 8) : 0x1ff;
+            const int cB = (i0 + k < mB) ? ((int)bB[i0 + k] << 8) : 0x1ff;
+            s.bch[k] = pack2(cA, cB);
+        }
     }
     {
         const int hd = hcol0p(i0, E, O);
         s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
     }
     s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.sh = s.hbot; s.se = s.hbot; s.mx = 0u;
+    s.cch2 = 0u; s.ach2 = 0u;
+    const unsigned k4 = (pmx_s & 0xffu) * 0x01010101u;
 
     const int nsteps = n + 64;
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
@@ -240,7 +265,8 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
             s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
         }
-        s.ach = pack2(naA << 8, naB << 8);
+        if (PERM) { s.ach = acgt_table(naA, k4); s.ach2 = acgt_table(naB, k4); }
+        else      s.ach = pack2(naA << 8, naB << 8);
         const int cn = t0 + 64 + ln;
         if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
         if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
@@ -260,16 +286,16 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             elided_frame<R>(s, ln, ae, +1, 0);
             { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep_elided<R>(s, po, pmx, pf2);
+            for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
             elided_frame<R>(s, ln, ae, -1, 64);
             // the 64 captured bottom-row entries (column t0-64+lane): row 64R below the top, 63-lane columns behind t0-1
             { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if (steady) {
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
 #pragma unroll 1
-            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
         const int cs = t0 - 64 + opaque(lane);
         if (store_bottom && cs >= 0 && cs < n) {
@@ -281,7 +307,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     fold_max<R>(s, acc);
 }
 
-template <int R>
+template <int R, bool PERM>
 __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
                                               int nA, int mA, int nB, int mB, int2* rowA, int2* rowB, int lane,
                                               int M, int E, int O,
@@ -299,8 +325,8 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     constexpr int BAND = 64 * R;
     for (int r0 = 0; r0 < mmax; r0 += BAND) {
         const bool last = r0 + BAND >= mmax;
-        if (r0 + BAND <= mmin) pband<R, false>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-        else                   pband<R, true>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        if (r0 + BAND <= mmin) pband<R, false, PERM>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        else                   pband<R, true, PERM>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
         if (!last) wave_mem_sync();
     }
     outA = wave_max(acc.mxA);
@@ -333,7 +359,10 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         const int nA = swa ? l2a : l1a, mA = swa ? l1a : l2a;
         const int nB = swb ? l2b : l1b, mB = swb ? l1b : l2b;
         int ra, rb;
-        pscore_couple<R>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
+        // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
+        const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
+        if (perm) pscore_couple<R, true>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
+        else      pscore_couple<R, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
         wave_mem_sync();
     }

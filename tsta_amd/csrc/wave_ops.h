@@ -54,6 +54,31 @@ __device__ __forceinline__ void lane_exchange(unsigned& cch, unsigned& hu, unsig
         : "vcc", "scc");
 }
 
+// lane_exchange for a column character that travels as TWO registers (the per-pair byte tables of the v_perm path)
+__device__ __forceinline__ void lane_exchange2(unsigned& cch, unsigned& cch2, unsigned& hu, unsigned& eu, unsigned& sh, unsigned& se,
+                                               unsigned& ach, unsigned& ach2, unsigned& th, unsigned& te, unsigned hbot, unsigned ebot)
+{
+    hu = hbot;
+    eu = ebot;
+    asm volatile(
+        "s_mov_b64 vcc, 1\n\t"
+        "v_cndmask_b32_dpp %0, %0, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %8, %8, %9, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_lshl_b64 vcc, 1, 63\n\t"
+        "v_cndmask_b32_dpp %3, %3, %1, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cndmask_b32_dpp %4, %4, %2, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_mov_b64 vcc, 1\n\t"
+        "v_cndmask_b32_dpp %1, %1, %6, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %2, %7, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(cch), "+v"(hu), "+v"(eu), "+v"(sh), "+v"(se), "+v"(ach), "+v"(th), "+v"(te), "+v"(cch2), "+v"(ach2)
+        :
+        : "vcc", "scc");
+}
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
