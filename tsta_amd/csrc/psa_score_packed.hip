@@ -240,16 +240,22 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     const unsigned k4 = (pmx_s & 0xffu) * 0x01010101u;
 
     const int nsteps = n + 64;
+    const int ae = -E;
+    bool in_star = false;        // lane state currently in the frame of the elided blocks (kept across consecutive ones)
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
         const int ln = opaque(lane);
+        int lag = 64;            // columns the lane has moved since the H* frame's reference column was set
         if (t0 > 0 && t0 < n) {
             // re-anchor both pairs to the band's top row at column t0
             fold_max<R>(s, acc);
             // (a pair whose columns are exhausted keeps its last anchor: its lanes hold garbage from here on)
             const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
             const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
-            const unsigned pd = pack2(nbA - acc.baseA, nbB - acc.baseB);
+            // (in the H* frame the reference column moves along with the block: +64|E| on everything)
+            const int star = in_star ? 64 * ae : 0;
+            const unsigned pd = pack2(nbA - acc.baseA - star, nbB - acc.baseB - star);
             acc.baseA = nbA; acc.baseB = nbB;
+            lag = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
             s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
@@ -272,22 +278,32 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
         bool elide = false;
-        if (!PARTIAL && steady && elide_ok) {
-            // can this block raise either pair's maximum?  (see pstep_elided)
-            unsigned v = pkmax(s.hd, s.th);
+        if (steady && elide_ok) {
+            // can this block raise either pair's maximum?  (see pstep_elided)  Rows beyond the end of a pair hold
+            // garbage that no real cell ever reads: they do not count.
+            const unsigned lane_s = in_star ? pack2(ae * ((ln - 32) * (R + 1)), ae * ((ln - 32) * (R + 1))) : 0u;
+            unsigned v = pkmax(PARTIAL ? (pksub(s.hd, lane_s) & (((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u))) : pksub(s.hd, lane_s),
+                               PARTIAL ? (s.th & (((mA > band_row0) ? 0xffffu : 0u) | ((mB > band_row0) ? 0xffff0000u : 0u))) : s.th);
 #pragma unroll
-            for (int k = 0; k < R; ++k) v = pkmax(v, s.hl[k]);
+            for (int k = 0; k < R; ++k) {
+                unsigned hv = s.hl[k];
+                if (in_star) hv = pksub(hv, pkadd(lane_s, pack2(ae * (k + 1), ae * (k + 1))));        // back to H'
+                if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);
+                v = pkmax(v, hv);
+            }
             const int ubA = wave_max((int)(v & 0xffffu)) - kBias + acc.baseA + (t0 + 64) * M;
             const int ubB = wave_max((int)(v >> 16)) - kBias + acc.baseB + (t0 + 64) * M;
             elide = ubA <= max(wave_max(acc.mxA), -100) && ubB <= max(wave_max(acc.mxB), -100);
         }
+        if (elide != in_star) {                        // frame change only where the kind of block changes
+            if (elide) elided_frame<R>(s, ln, ae, +1, 0);
+            else       elided_frame<R>(s, ln, ae, -1, lag);
+            in_star = elide;
+        }
         if (elide) {
-            const int ae = -E;
-            elided_frame<R>(s, ln, ae, +1, 0);
             { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
 #pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
-            elided_frame<R>(s, ln, ae, -1, 64);
             // the 64 captured bottom-row entries (column t0-64+lane): row 64R below the top, 63-lane columns behind t0-1
             { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if (steady) {
