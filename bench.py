@@ -30,7 +30,11 @@ from tsta_amd.sharding import gather_scores  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 int32 lane-ops/s
-VALU_OPS_PER_CELL = 6.09              # K1p hot loop: 195 VALU instructions per step of 32 cells (5.5 per cell: 6 v_pk_max/min + 5 add/sub/xor per 2 cells; + 8 DPP, moves, running max per step)
+# K1p steady-state loop (R=32, pure-ACGT couple, block proven unable to raise the maximum): 532 VALU instructions per
+# 2 steps of 64 cells = 8 per cell pair (f-sub, v_perm lookup, diag-sub, 4 v_pk_max, g-sub) + 10 per step for the lane
+# hand-off.  The generic loop (any bytes, running max kept) is 11.3 per cell pair = 5.66 per cell.
+VALU_OPS_PER_CELL = 4.16
+VALU_OPS_PER_CELL_GENERIC = 5.66
 
 
 def parse():
@@ -41,15 +45,26 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=int(os.environ.get("TSTA_BENCH_PAIRS", 8192)))
     ap.add_argument("--len", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generic", action="store_true", help="skip the extra pass down the generic kernel path")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
 
 
 def make_shard(n_pairs, length, seed, device):
-    """Synthetic iid uniform ACGT, generated on the GPU (inputs are HBM-resident before the timed region)."""
+    """Synthetic iid uniform ACGT, generated on the GPU (inputs are HBM-resident before the timed region).
+    TSTA_BENCH_RELATED=<percent> (experiments only, not the BASELINE workload): the second sequence of every pair is the
+    first with that percentage of substituted positions instead of an independent draw."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     idx = torch.randint(0, 4, (2 * n_pairs * length,), generator=g, device=device, dtype=torch.uint8)
+    related = float(os.environ.get("TSTA_BENCH_RELATED", 0))
+    if related > 0:
+        v = idx.view(n_pairs, 2, length)
+        for lo in range(0, n_pairs, 256):
+            a = v[lo:lo + 256, 0]
+            hit = torch.rand(a.shape, generator=g, device=device) < related / 100.0
+            sub = torch.randint(1, 4, a.shape, generator=g, device=device, dtype=torch.uint8)
+            v[lo:lo + 256, 1] = torch.where(hit, (a + sub) % 4, a)
     alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     seqs = alpha[idx.long()] if idx.numel() < (1 << 28) else torch.cat(
         [alpha[c.long()] for c in idx.split(1 << 28)])
@@ -179,6 +194,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same shard once more down the generic path (any byte alphabet, running max kept in every block): what the
+    # kernel does when neither of its two data-dependent shortcuts applies.  Results must be identical.
+    generic_ms = None
+    if world == 1 and not args.no_generic:
+        first = scores.clone()
+        eng.set_option("psa_elide", 0); eng.set_option("psa_perm", 0)
+        with torch.cuda.stream(tstream):
+            step()
+            torch.cuda.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(); step(); g1.record()
+            torch.cuda.synchronize()
+        generic_ms = g0.elapsed_time(g1)
+        eng.set_option("psa_elide", 1); eng.set_option("psa_perm", 1)
+        assert torch.equal(first, scores), "generic and shortcut paths disagree"
+
     # sanity on the result of the last step: random DNA gives a degenerate maxsorce in a tiny range
     sc = scores.cpu().numpy()
     assert sc.min() >= -100 and sc.max() < 2 * L, (sc.min(), sc.max())
@@ -204,15 +235,18 @@ def main():
             "dtype": "u16 packed x2 (biased, int32 per-pair base)", "data": "synthetic",
             "config": {"workload": "BASELINE config #5 per-GPU shard: %d pairs/GPU of %d x %d random DNA, affine gap "
                                    "M=2 X=-5 E=-2 O=-4, score only (maxsorce), inputs HBM-resident" % (P, L, L),
+                       "kernel_path": "psa_score_packed_kernel<32,2>: pure-ACGT couples use the v_perm mismatch lookup; blocks whose "
+                                      "entering scores bound them below the pair's current maximum skip the running max "
+                                      "(every cell is still computed; exact for any input)",
                        "pairs_per_gpu": P, "len": L, "parallelism": "pairs sharded x%d, RCCL all-gather of scores" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "psa_score_packed_kernel", "kernel_ms": kern_ms,
                          "note": "integer max-plus recurrence: VALU-issue-bound, HBM fraction is ~0 by construction "
                                  "(SURVEY 8d); see valu_roofline"},
-            # data-sheet VALU peak (one wave64 instruction per 2 cycles per SIMD) and, next to it, the issue rate this
-            # dependent integer stream actually sustains on gfx950 (one per ~4 cycles per SIMD at 2.39 GHz, measured with
-            # tools/step_microbench.hip and in-kernel s_memtime stamps)
+            # data-sheet VALU peak (one wave64 instruction per 2 cycles per SIMD, reached only by pure add/sub/logic streams)
+            # and, next to it, the rate every stream containing max/min/perm/packed ops sustains on gfx950: one wave64
+            # instruction per 4 cycles per SIMD (16 lanes/cycle; tools/cell_microbench.hip)
             "valu_roofline": {"ops_per_cell": VALU_OPS_PER_CELL,
                               "measured_issue_ceiling": 256 * 4 * 64 * 2.39e9 / 4.0 / 1e12,
                               "frac_of_measured_ceiling": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / (256 * 4 * 64 * 2.39e9 / 4.0),
@@ -220,6 +254,10 @@ def main():
                               "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
                               "frac": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS},
         }
+        if generic_ms is not None:
+            out["generic_path"] = {"value": float(P) * L * L / (generic_ms * 1e-3) / 1e9, "unit": "GCUPS", "ms": generic_ms,
+                                   "ops_per_cell": VALU_OPS_PER_CELL_GENERIC,
+                                   "note": "same shard, psa_elide=0 psa_perm=0: no data-dependent shortcut; identical scores"}
         if not args.no_cpu_baseline and world == 1:
             n_s = args.cpu_sample_pairs or min(256, max(4, int(round(16 * (50_000.0 / L) ** 2))))
             out["cpu_baseline"] = cpu_baseline(L, n_s)

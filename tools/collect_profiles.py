@@ -43,15 +43,15 @@ fe = pmc("prof_fetch", "FETCH_SIZE", "psa_score_packed")
 wr = pmc("prof_write", "WRITE_SIZE", "psa_score_packed")
 if fe and wr:
     fb, wb = fe[0]["value_kb"] * 1024, wr[0]["value_kb"] * 1024
-    t = {"kernel": "psa_score_packed_kernel<16,4>", "pairs_per_gpu": 8192, "len": 50000,
+    t = {"kernel": "psa_score_packed_kernel<32,2>", "pairs_per_gpu": 8192, "len": 50000,
          "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
          "fetch_correction": "x2: gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM); the expected "
-                             "boundary-row reads (8192 pairs x 49 bands x 50000 columns x 8 B = 160.6 GB) + sequence re-reads agree with 2x raw",
+                             "boundary-row reads (8192 pairs x 24 band hand-offs x 50000 columns x 8 B = 78.6 GB) + sequence re-reads agree with 2x raw",
          "hbm_bytes_per_launch": 2 * fb + wb, "pmc_rows": fe + wr,
-         "what_it_is": "band hand-off rows ({H,Ebar} int32 per column per 1024-row band), i.e. workspace traffic, ~1% of HBM bandwidth; "
+         "what_it_is": "band hand-off rows ({H,Ebar} int32 per column per 2048-row band), i.e. workspace traffic, <1% of HBM bandwidth; "
                        "algorithmic bytes are 0.82 GB per launch",
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
-                    "--no-cpu-baseline (separate passes)"}
+                    "--no-cpu-baseline --no-generic (separate passes)"}
     json.dump(t, open(os.path.join(out, "traffic_psa_score.json"), "w"), indent=1)
 for f, name in (("bench_default.json", "bench_default"), ("bench_prof.json", "bench_under_rocprof"), ("configs.jsonl", "configs")):
     if os.path.exists(os.path.join(base, f)):
