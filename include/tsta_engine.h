@@ -92,6 +92,23 @@ int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint8_t* s1, in
                    const uint8_t* s2, int64_t l2, int32_t* maxscore, char** row_a, char** row_b,
                    int64_t* out_len);
 
+/* Many independent pairs with traceback: what a loop of TSTA_psa processes would produce (the reference has no batch
+ * mode: one process per pair, psa.c:539-668), with the pairs' fills in flight together on the device.  Inputs as for
+ * tsta_psa_score_batch (host pointers).  out[k].row_a / row_b are malloc'd (free them with tsta_alignments_free or
+ * each with tsta_free); row_a belongs to the longer input of pair k.  Pairs are processed in groups whose trace
+ * matrices (1 byte per DP cell) fit the device together; a single pair too large for it returns TSTA_ERR_OOM. */
+typedef struct tsta_alignment {
+    int32_t maxscore; int32_t reserved;
+    int64_t len;                    /* length of both gapped rows */
+    char*   row_a;
+    char*   row_b;
+} tsta_alignment;
+
+int  tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                          int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                          const int64_t* off2, const int32_t* len2, tsta_alignment* out);
+void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
+
 /* ------------------------------------------------------------------------------------------------
  * POA fill  ==  one control() wavefront of TSTA_msa without node_fuse (c-t-simd.c:979-1045 driving
  * block_alignment :602-657 / block_line_alignment :165-599): aligns `seq` (length n, 'N'-free) to a DAG

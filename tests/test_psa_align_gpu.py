@@ -114,3 +114,100 @@ def test_fuzz_alignment_vs_oracle(eng):
         got = eng.psa_align(a, b, tsta_amd.Params(**sc))
         o = util.oracle_align(a, b, **sc)
         assert got == (o[0], o[2], o[3]), (trial, sc, n, len(b))
+
+
+# ---- tsta_psa_align_batch: many pairs in flight together (what a loop of TSTA_psa processes would produce) ----------
+
+def _ragged_cases(seed, count, lo, hi):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for t in range(count):
+        n = int(rng.integers(lo, hi)); m = int(rng.integers(lo, hi))
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = t % 4
+        if kind == 0:
+            b = util.mutate(a, int(rng.integers(1 << 30)), 0.1)[:m]
+        elif kind == 1:
+            b = util.random_dna(int(rng.integers(1 << 30)), m)
+        elif kind == 2:
+            b = util.low_complexity(int(rng.integers(1 << 30)), m, 2)
+        else:
+            b = np.concatenate([a[: n // 3], a[2 * n // 3:]])
+        if len(b) == 0:
+            b = a[:1]
+        cases.append((a, b) if t % 3 else (b, a))
+    return cases
+
+
+def test_batch_golden_output_bytes(eng):
+    by_params = {}
+    for c in GOLDEN:
+        by_params.setdefault(tuple(sorted(c["scoring"].items())), []).append(c)
+    for key, cs in by_params.items():
+        res = eng.psa_align_batch([case_inputs(c) for c in cs], tsta_amd.Params(**dict(key)))
+        for c, (ms, ra, rb) in zip(cs, res):
+            assert ms == c["maxsorce"]
+            out = output_bytes(ra, rb)
+            assert len(out) == c["out_size"] and hashlib.md5(out).hexdigest() == c["out_md5"], c["name"] if "name" in c else c
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=10, X=-10, E=-3, O=-12), dict(M=1, X=-1, E=-1, O=0)])
+def test_batch_ragged_vs_oracle(eng, scoring):
+    e = np.zeros(0, dtype=np.uint8)
+    cases = _ragged_cases(41, 40, 1, 2500) + [(e, util.random_dna(1, 50)), (util.random_dna(2, 7), e), (e, e)]
+    res = eng.psa_align_batch(cases, tsta_amd.Params(**scoring))
+    assert len(res) == len(cases)
+    for (s1, s2), got in zip(cases, res):
+        o = util.oracle_align(s1, s2, **scoring)
+        assert got == (o[0], o[2], o[3]), (len(s1), len(s2), scoring)
+    # identical to the one-pair entry point
+    for (s1, s2), got in list(zip(cases, res))[:6]:
+        assert got == eng.psa_align(s1, s2, tsta_amd.Params(**scoring))
+
+
+def test_batch_many_bands_uses_tall_bands_and_long_tiles(eng):
+    # enough bands in flight (>= 16 per CU at 256 rows each) switch the group to R=4 / T=256; results do not change,
+    # also with the other instantiation forced and with groups split by a small workspace budget
+    cases = _ragged_cases(43, 24, 3000, 9000) + _ragged_cases(44, 200, 1500, 2500)
+    want = [util.oracle_align(s1, s2) for s1, s2 in cases[:24]]
+    res = eng.psa_align_batch(cases)
+    for w, got in zip(want, res):
+        assert got == (w[0], w[2], w[3])
+    try:
+        eng.set_option("trace_rows", 2); eng.set_option("trace_tile", 128)
+        res2 = eng.psa_align_batch(cases)
+    finally:
+        eng.set_option("trace_rows", 0); eng.set_option("trace_tile", 0)
+    assert res2 == res
+
+
+def test_batch_split_into_groups_by_budget(eng, monkeypatch):
+    cases = _ragged_cases(45, 30, 800, 3000)
+    res = eng.psa_align_batch(cases)
+    monkeypatch.setenv("TSTA_ALIGN_BUDGET_MB", "40")          # a few pairs per group
+    res2 = eng.psa_align_batch(cases)
+    assert res2 == res
+    monkeypatch.setenv("TSTA_ALIGN_BUDGET_MB", "1")           # not even one pair fits: clean error, nothing leaked
+    with pytest.raises(tsta_amd.TstaError):
+        eng.psa_align_batch(cases)
+    monkeypatch.delenv("TSTA_ALIGN_BUDGET_MB")
+    assert eng.psa_align_batch(cases[:3]) == res[:3]
+
+
+def test_batch_full_size_50k_properties(eng):
+    # BASELINE-size pairs with traceback, several in flight: row lengths, gap-free projections and the score of the
+    # alignment equal to H(m,n)'s defining recurrence value computed from the rows themselves
+    L = 50_000
+    cases = []
+    for i in range(6):
+        a = util.random_dna(900 + i, L)
+        cases.append((a, util.mutate(a, 950 + i, 0.05)[:L] if i % 2 == 0 else util.random_dna(970 + i, L)))
+    res = eng.psa_align_batch(cases)
+    for (s1, s2), (ms, ra, rb) in zip(cases, res):
+        assert len(ra) == len(rb)
+        la, lb = (s1, s2) if len(s1) >= len(s2) else (s2, s1)
+        assert ra.replace(b"-", b"") == bytes(la) and rb.replace(b"-", b"") == bytes(lb)
+        oms, oend = util.oracle_scores(s1, s2)
+        assert ms == oms and util.alignment_score(ra, rb) == oend
+    one = eng.psa_align(*cases[0])
+    assert one == res[0]

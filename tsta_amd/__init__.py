@@ -18,12 +18,18 @@ lib_path = os.path.join(_HERE, "lib", "libtsta_hip.so")
 EXPORTED_SYMBOLS = [
     "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
-    "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align",
+    "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align", "tsta_psa_align_batch", "tsta_alignments_free",
 ]
 
 
 class TstaError(RuntimeError):
     pass
+
+
+class Alignment(C.Structure):
+    """tsta_alignment (include/tsta_engine.h)."""
+    _fields_ = [("maxscore", C.c_int32), ("reserved", C.c_int32), ("len", C.c_int64), ("row_a", C.c_void_p),
+                ("row_b", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -72,6 +78,10 @@ def lib():
         L.tsta_psa_score_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
         L.tsta_psa_score_batch_dev.restype = C.c_int
         L.tsta_psa_score_batch_dev.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.tsta_psa_align_batch.restype = C.c_int
+        L.tsta_psa_align_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, C.POINTER(Alignment)]
+        L.tsta_alignments_free.restype = None
+        L.tsta_alignments_free.argtypes = [C.POINTER(Alignment), i64]
         L.tsta_psa_align.restype = C.c_int
         L.tsta_psa_align.argtypes = [vp, C.POINTER(Params), vp, i64, vp, i64, C.POINTER(i32), C.POINTER(vp),
                                      C.POINTER(vp), C.POINTER(i64)]
@@ -173,6 +183,22 @@ class Engine:
         a = C.string_at(ra, ln.value); b = C.string_at(rb, ln.value)
         lib().tsta_free(ra); lib().tsta_free(rb)
         return int(ms.value), a, b
+
+    def psa_align_batch(self, pairs, params=None):
+        """pairs: list of (s1, s2) in CLI order.  -> list of (maxsorce, row_a, row_b), one per pair, as a loop of
+        TSTA_psa runs would write them; the pairs' fills are in flight together on the device."""
+        params = params or Params()
+        if len(pairs) == 0:
+            return []
+        seqs, o1, l1, o2, l2 = pack_pairs(pairs)
+        sq = seqs if len(seqs) else np.zeros(1, dtype=np.uint8)
+        out = (Alignment * len(pairs))()
+        rc = lib().tsta_psa_align_batch(self._h, C.byref(params), len(pairs), _ptr(sq), len(seqs), _ptr(o1), _ptr(l1),
+                                        _ptr(o2), _ptr(l2), out)
+        self._check(rc, "tsta_psa_align_batch")
+        res = [(int(o.maxscore), C.string_at(o.row_a, o.len), C.string_at(o.row_b, o.len)) for o in out]
+        lib().tsta_alignments_free(out, len(pairs))
+        return res
 
     # ---- POA fill (one control() wavefront of TSTA_msa) ---------------------------------------------
     def poa_fill(self, pred_off, pred, base, is_sink, seq, params=None, want_trace=True):

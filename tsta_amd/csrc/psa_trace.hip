@@ -1,4 +1,6 @@
-// psa_trace.hip — K2 (fill with packed trace) + K3 (traceback walker) for ONE pair: tsta_psa_align.
+// psa_trace.hip — K2 (fill with packed trace) + K3 (traceback walker): tsta_psa_align (one pair) and
+// tsta_psa_align_batch (many independent pairs in flight at once; each pair is a "job", the bands of all jobs of a
+// group share the launches).
 //
 // Replaces the TRACE build's fill (row() with the back/fback/eback stores, psa/psa.c:294-327,358-362, driven
 // by the block wavefront :593-639) and trace() (psa.c:435-518).
@@ -37,17 +39,26 @@ namespace tsta {
 
 constexpr int kNegInfT = -(1 << 30);
 
-struct PsaTraceArgs {
-    const uint8_t* a; int n;        // columns (longer sequence)
-    const uint8_t* b; int m;        // rows
+// one oriented pair (a = columns = longer sequence, b = rows) of a group, device-resident
+struct TraceJob {
+    const uint8_t* a; const uint8_t* b;
+    int n, m;
     int2*     rows;                 // [W+1][row_stride]: rows[w] = top row of band w ({H, Ebar} per column)
     int64_t   row_stride;
     int*      state;                // [W][NS][64] per-lane DP state between tiles
     uint8_t*  trace;                // [W][band_bytes]
     int64_t   band_bytes;
-    int       W, T, d, S_total;     // bands, tile length (steps), launch index, total steps per band (mult. of 64)
-    int       w_lo, w_hi;           // active band range of this launch
-    int       M, X, E, O;
+    int       W, S_total;           // bands, total steps per band (multiple of 64)
+    int       band0;                // index of this job's first band among the bands of the group
+    uint8_t*  ops;                  // walker output (see WalkArgs)
+    int*      out;                  // [8]: maxsorce, H(m,n), #ops, final i, final j
+};
+
+struct PsaTraceArgs {
+    const TraceJob* jobs; int n_jobs;
+    int g_lo, g_hi;                 // range of group-wide band indices this launch covers
+    int T, d;                       // tile length (steps), launch index
+    int M, X, E, O;
 };
 
 template <int R> struct TraceCfg {
@@ -147,21 +158,28 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     constexpr int NS = TraceCfg<R>::NS;
     constexpr int SPB = TraceCfg<R>::SPB;
     const int lane = threadIdx.x & 63;
-    const int w = A.w_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= A.w_hi) return;
+    const int g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (g >= A.g_hi) return;
+    int lo = 0, hi = A.n_jobs - 1;              // job = last one whose first band is <= g
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.jobs[mid].band0 <= g) lo = mid; else hi = mid - 1; }
+    const TraceJob& J = A.jobs[lo];
+    const int w = g - J.band0;
+    if (w >= J.W) return;
     const int shift = w * (A.T + 64);
     int s0 = A.d * A.T - shift, s1 = (A.d + 1) * A.T - shift;
-    s0 = max(0, min(s0, A.S_total));
-    s1 = max(0, min(s1, A.S_total));
+    s0 = max(0, min(s0, J.S_total));
+    s1 = max(0, min(s1, J.S_total));
     if (s0 >= s1) return;
 
-    const int n = A.n, m = A.m, M = A.M, X = A.X, E = A.E, O = A.O;
+    const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O;
+    const uint8_t* __restrict__ seq_a = J.a;
+    const uint8_t* __restrict__ seq_b = J.b;
     const int i0 = w * 64 * R + lane * R;
     const int nvalid = m - i0;
-    int* st = A.state + (size_t)w * NS * 64 + lane;
+    int* st = J.state + (size_t)w * NS * 64 + lane;
     TLane<R> s;
 #pragma unroll
-    for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < m) ? (int)A.b[i0 + k] : 0x100;
+    for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < m) ? (int)seq_b[i0 + k] : 0x100;
     if (s0 == 0) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -179,14 +197,14 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     }
     s.sh = 0; s.se = 0;
 
-    const int2* __restrict__ top = A.rows + (size_t)w * A.row_stride;
-    int2* __restrict__ bot = A.rows + (size_t)(w + 1) * A.row_stride;
-    uint8_t* tband = A.trace + (size_t)w * A.band_bytes;
+    const int2* __restrict__ top = J.rows + (size_t)w * J.row_stride;
+    int2* __restrict__ bot = J.rows + (size_t)(w + 1) * J.row_stride;
+    uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
 
     for (int t0 = s0; t0 < s1; t0 += 64) {
         const int c = t0 + lane;
         int2 nt = make_int2(0, 0); int na = 0;
-        if (c < n) { nt = top[c]; na = A.a[c]; }
+        if (c < n) { nt = top[c]; na = seq_a[c]; }
         s.th = nt.x; s.te = nt.y; s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
         if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq);
@@ -200,18 +218,24 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     st[(2 * R + 3) * 64] = s.cch; st[(2 * R + 4) * 64] = s.mx;
 }
 
-// boundary row of the matrix (psa.c:221-226) into rows[0]
-__global__ void psa_trace_init_kernel(int2* row0, int n, int E, int O)
+// boundary row of the matrix (psa.c:221-226) into rows[0] of every job (blockIdx.y = job)
+__global__ void psa_trace_init_kernel(const TraceJob* jobs, int E, int O)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) { const int h = O + (c + 1) * E; row0[c] = make_int2(h, h + O); }
+    const TraceJob& J = jobs[blockIdx.y];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < J.n; c += gridDim.x * blockDim.x) {
+        const int h = O + (c + 1) * E;
+        J.rows[c] = make_int2(h, h + O);
+    }
 }
 
-// out[0] = max over all lanes' running maxima (floored at -100, psa.c:590), out[1] = H(m,n)
+// per job (blockIdx.x): out[0] = max over all lanes' running maxima (floored at -100, psa.c:590), out[1] = H(m,n)
 template <int R>
-__global__ void psa_trace_finish_kernel(const int* state, int W, int m, int* out)
+__global__ void psa_trace_finish_kernel(const TraceJob* jobs)
 {
     constexpr int NS = TraceCfg<R>::NS;
+    const TraceJob& J = jobs[blockIdx.x];
+    const int* state = J.state;
+    const int W = J.W, m = J.m;
     int mx = kNegInfT;
     for (int idx = threadIdx.x; idx < W * 64; idx += blockDim.x) {
         const int w = idx / 64, lane = idx % 64;
@@ -222,9 +246,9 @@ __global__ void psa_trace_finish_kernel(const int* state, int W, int m, int* out
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
     if (threadIdx.x == 0) {
-        out[0] = max(red[0], -100);
+        J.out[0] = max(red[0], -100);
         const int rr = (m - 1) % (64 * R), w = (m - 1) / (64 * R);
-        out[1] = state[(size_t)w * NS * 64 + (2 * (rr % R)) * 64 + rr / R];
+        J.out[1] = state[(size_t)w * NS * 64 + (2 * (rr % R)) * 64 + rr / R];
     }
 }
 
@@ -238,8 +262,13 @@ struct WalkArgs {
 };
 
 template <int R, int NQ>
-__global__ __launch_bounds__(64) void psa_walk_kernel(WalkArgs A)
+__global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
 {
+    WalkArgs A;
+    {
+        const TraceJob& J = jobs[blockIdx.x];
+        A.trace = J.trace; A.band_bytes = J.band_bytes; A.n = J.n; A.m = J.m; A.ops = J.ops; A.out = J.out;
+    }
     constexpr int SPB = TraceCfg<R>::SPB;
     constexpr int BAND = 64 * R;
     __shared__ uint4 win[NQ * 64];
@@ -337,86 +366,164 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(WalkArgs A)
     if (lane == 0) { A.out[2] = cnt; A.out[3] = i; A.out[4] = j; }
 }
 
-// TRACE = true: fill with packed trace + on-device walk (tsta_psa_align).  TRACE = false: the same pipelined fill of
-// ONE pair over many waves, score only (a single long pair would otherwise occupy one wave of the batch kernel).
+// One oriented pair on the host side of a group, and what comes back for it.
+struct HostJob {
+    const uint8_t* a; int n;        // columns (host pointer)
+    const uint8_t* b; int m;        // rows
+    int32_t maxscore = -100, end_score = 0;
+    std::vector<uint8_t> ops;       // walker output, from the end of the alignment backwards
+    int fi = 0, fj = 0;             // cell at which the walk stopped
+};
+
+template <int R> struct JobGeom {
+    int W, S_total; int64_t row_stride, band_bytes;
+    size_t rows_bytes, state_bytes, trace_bytes, ops_bytes, seq_bytes;
+    JobGeom(int n, int m, bool trace) {
+        W = (m + 64 * R - 1) / (64 * R);
+        S_total = (n + 64 + 63) / 64 * 64;
+        row_stride = S_total + 64;
+        band_bytes = (int64_t)S_total * 64 * R;
+        rows_bytes = (size_t)(W + 1) * row_stride * sizeof(int2);
+        state_bytes = (size_t)W * TraceCfg<R>::NS * 64 * sizeof(int);
+        trace_bytes = trace ? (size_t)W * band_bytes : 0;
+        ops_bytes = trace ? ((size_t)n + m + 64 + 63) / 64 * 64 : 0;
+        seq_bytes = ((size_t)n + m + 64 + 63) / 64 * 64;
+    }
+    size_t total() const { return rows_bytes + state_bytes + trace_bytes + ops_bytes + seq_bytes + 256; }
+};
+
+// TRACE = true: fill with packed trace + on-device walk of every job of the group.  TRACE = false: the same pipelined
+// fill, score only (psa_score_single_pair: a single long pair would otherwise occupy one wave of the batch kernel).
+// All jobs of the group are in flight together: launch d advances every band of every job by one T-step tile.
 template <int R, bool TRACE>
-static int run_align(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m,
-                     int32_t* maxscore, int32_t* end_score, std::vector<uint8_t>& ops, int& fi, int& fj)
+static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs, int T)
 {
-    constexpr int NS = TraceCfg<R>::NS;
-    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 64;   // knob "trace_tile"
-    const int W = (m + 64 * R - 1) / (64 * R);
-    const int S_total = (n + 64 + 63) / 64 * 64;
-    const int64_t row_stride = S_total + 64;
-    const int64_t band_bytes = (int64_t)S_total * 64 * R;
     hipStream_t s = e->stream;
+    std::vector<TraceJob> tj((size_t)n_jobs);
+    size_t rows_b = 0, state_b = 0, trace_b = 0, ops_b = 0, seq_b = 0;
+    int64_t total_bands = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const JobGeom<R> g(jobs[j].n, jobs[j].m, TRACE);
+        rows_b += g.rows_bytes; state_b += g.state_bytes; trace_b += g.trace_bytes; ops_b += g.ops_bytes; seq_b += g.seq_bytes;
+        total_bands += g.W;
+    }
+    if (total_bands > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
     int rc;
-    if ((rc = e->reserve(e->in_seqs, (size_t)n + m + 64, "hipMalloc(seqs)")) ||
-        (rc = e->reserve(e->rows, (size_t)(W + 1) * row_stride * sizeof(int2), "hipMalloc(rows)")) ||
-        (rc = e->reserve(e->scratch, (size_t)W * NS * 64 * sizeof(int), "hipMalloc(state)")) ||
-        (TRACE && (rc = e->reserve(e->trace, (size_t)W * band_bytes, "hipMalloc(trace)"))) ||
-        (TRACE && (rc = e->reserve(e->scratch2, (size_t)n + m + 64, "hipMalloc(ops)"))))
+    if ((rc = e->reserve(e->in_seqs, seq_b, "hipMalloc(seqs)")) ||
+        (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
+        (rc = e->reserve(e->scratch, state_b, "hipMalloc(state)")) ||
+        (rc = e->reserve(e->in_meta, (size_t)n_jobs * (sizeof(TraceJob) + 8 * sizeof(int)) + 256, "hipMalloc(jobs)")) ||
+        (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
+        (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
-    uint8_t* d_a = reinterpret_cast<uint8_t*>(e->in_seqs.p);
-    uint8_t* d_b = d_a + n;
-    int* d_out = reinterpret_cast<int*>(e->counter.p);
-    if ((rc = e->check(hipMemcpyAsync(d_a, a, n, hipMemcpyHostToDevice, s), "H2D a")) ||
-        (rc = e->check(hipMemcpyAsync(d_b, b, m, hipMemcpyHostToDevice, s), "H2D b")))
+    char* d_seq = reinterpret_cast<char*>(e->in_seqs.p);
+    char* d_rows = reinterpret_cast<char*>(e->rows.p);
+    char* d_state = reinterpret_cast<char*>(e->scratch.p);
+    char* d_trace = reinterpret_cast<char*>(e->trace.p);
+    char* d_ops = reinterpret_cast<char*>(e->scratch2.p);
+    TraceJob* d_jobs = reinterpret_cast<TraceJob*>(e->in_meta.p);
+    int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + ((size_t)n_jobs * sizeof(TraceJob) + 255) / 256 * 256);
+    int band0 = 0, max_n = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const JobGeom<R> g(jobs[j].n, jobs[j].m, TRACE);
+        TraceJob& J = tj[j];
+        J.a = reinterpret_cast<const uint8_t*>(d_seq); J.b = J.a + jobs[j].n; J.n = jobs[j].n; J.m = jobs[j].m;
+        if ((rc = e->check(hipMemcpyAsync(d_seq, jobs[j].a, jobs[j].n, hipMemcpyHostToDevice, s), "H2D a")) ||
+            (rc = e->check(hipMemcpyAsync(d_seq + jobs[j].n, jobs[j].b, jobs[j].m, hipMemcpyHostToDevice, s), "H2D b")))
+            return rc;
+        J.rows = reinterpret_cast<int2*>(d_rows); J.row_stride = g.row_stride;
+        J.state = reinterpret_cast<int*>(d_state);
+        J.trace = reinterpret_cast<uint8_t*>(d_trace); J.band_bytes = g.band_bytes;
+        J.W = g.W; J.S_total = g.S_total; J.band0 = band0;
+        J.ops = reinterpret_cast<uint8_t*>(d_ops); J.out = d_out + 8 * j;
+        d_seq += g.seq_bytes; d_rows += g.rows_bytes; d_state += g.state_bytes; d_trace += g.trace_bytes; d_ops += g.ops_bytes;
+        band0 += g.W; max_n = std::max(max_n, jobs[j].n);
+    }
+    if ((rc = e->check(hipMemcpyAsync(d_jobs, tj.data(), tj.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D jobs")))
         return rc;
 
     PsaTraceArgs A;
-    A.a = d_a; A.n = n; A.b = d_b; A.m = m;
-    A.rows = reinterpret_cast<int2*>(e->rows.p); A.row_stride = row_stride;
-    A.state = reinterpret_cast<int*>(e->scratch.p);
-    A.trace = reinterpret_cast<uint8_t*>(e->trace.p); A.band_bytes = band_bytes;
-    A.W = W; A.T = T; A.S_total = S_total; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
+    A.jobs = d_jobs; A.n_jobs = n_jobs; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
 
     e->timing_begin(s);
-    hipLaunchKernelGGL(psa_trace_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A.rows, n, p->E, p->O);
+    hipLaunchKernelGGL(psa_trace_init_kernel, dim3((unsigned)std::min(64, (max_n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, s,
+                       d_jobs, p->E, p->O);
     int launches = 1;
-    // band w may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
-    const int64_t D = ((int64_t)S_total + (int64_t)(W - 1) * (T + 64) + T - 1) / T;
+    // band w of a job may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
+    int64_t D = 0;
+    for (int j = 0; j < n_jobs; ++j)
+        D = std::max<int64_t>(D, ((int64_t)tj[j].S_total + (int64_t)(tj[j].W - 1) * (T + 64) + T - 1) / T);
     for (int64_t d = 0; d < D; ++d) {
-        // active bands: S_w(d) > 0  and  S_w(d-1) < S_total
-        int64_t w_hi = ((d + 1) * T + (T + 64) - 1) / (T + 64);           // first w with S_w(d) <= 0
-        int64_t w_lo = (d * T - S_total) / (T + 64);                       // conservative lower bound
-        if (d * T - S_total < 0) w_lo = 0;
-        w_lo = std::max<int64_t>(0, w_lo); w_hi = std::min<int64_t>(W, w_hi);
-        if (w_lo >= w_hi) continue;
-        A.d = (int)d; A.w_lo = (int)w_lo; A.w_hi = (int)w_hi;
-        const int blocks = (int)((w_hi - w_lo + 3) / 4);
+        // group-wide range of bands with work in this launch: per job, S_w(d) > 0 and S_w(d-1) < S_total
+        int64_t g_lo = total_bands, g_hi = 0;
+        for (int j = 0; j < n_jobs; ++j) {
+            int64_t w_hi = ((d + 1) * T + (T + 64) - 1) / (T + 64);           // first w with S_w(d) <= 0
+            int64_t w_lo = (d * T - tj[j].S_total < 0) ? 0 : (d * T - tj[j].S_total) / (T + 64);   // conservative
+            w_hi = std::min<int64_t>(tj[j].W, w_hi);
+            if (w_lo >= w_hi) continue;
+            g_lo = std::min(g_lo, tj[j].band0 + w_lo); g_hi = std::max(g_hi, tj[j].band0 + w_hi);
+        }
+        if (g_lo >= g_hi) continue;
+        A.d = (int)d; A.g_lo = (int)g_lo; A.g_hi = (int)g_hi;
+        const int blocks = (int)((g_hi - g_lo + 3) / 4);
         hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3(blocks), dim3(256), 0, s, A);
         ++launches;
     }
-    hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(1), dim3(256), 0, s, A.state, W, m, d_out);
-    WalkArgs Wk;
-    Wk.trace = A.trace; Wk.band_bytes = band_bytes; Wk.n = n; Wk.m = m;
-    Wk.ops = reinterpret_cast<uint8_t*>(e->scratch2.p); Wk.out = d_out;
-    if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(1), dim3(64), 0, s, Wk);
+    hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_jobs), dim3(256), 0, s, d_jobs);
+    if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(n_jobs), dim3(64), 0, s, d_jobs);
     launches += 2;
     e->n_launches = launches;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "psa_align launches"))) return rc;
-    int h_out[8];
-    if ((rc = e->check(hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H out")) ||
+    std::vector<int> h_out((size_t)n_jobs * 8);
+    if ((rc = e->check(hipMemcpyAsync(h_out.data(), d_out, h_out.size() * sizeof(int), hipMemcpyDeviceToHost, s), "D2H out")) ||
         (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
         return rc;
-    *maxscore = h_out[0]; *end_score = h_out[1];
-    if (!TRACE) return TSTA_OK;
-    const int cnt = h_out[2]; fi = h_out[3]; fj = h_out[4];
-    if (cnt < 0 || cnt > n + m) { e->set_error("walker returned %d ops", cnt); return TSTA_ERR_INTERNAL; }
-    ops.resize(cnt);
-    if (cnt && (rc = e->check(hipMemcpy(ops.data(), Wk.ops, cnt, hipMemcpyDeviceToHost), "D2H ops"))) return rc;
-    return TSTA_OK;
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs[j].maxscore = h_out[8 * j]; jobs[j].end_score = h_out[8 * j + 1];
+        if (!TRACE) continue;
+        const int cnt = h_out[8 * j + 2]; jobs[j].fi = h_out[8 * j + 3]; jobs[j].fj = h_out[8 * j + 4];
+        if (cnt < 0 || cnt > jobs[j].n + jobs[j].m) { e->set_error("walker returned %d ops", cnt); return TSTA_ERR_INTERNAL; }
+        jobs[j].ops.resize(cnt);
+        if (cnt && (rc = e->check(hipMemcpyAsync(jobs[j].ops.data(), tj[j].ops, cnt, hipMemcpyDeviceToHost, s), "D2H ops"))) return rc;
+    }
+    return e->check(hipStreamSynchronize(s), "psa_align sync");
 }
 
 // Score-only fill of ONE oriented pair (a = columns, b = rows; host pointers) spread over the whole chip.
 int psa_score_single_pair(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m, int32_t* maxscore)
 {
-    std::vector<uint8_t> ops;
-    int fi = 0, fj = 0;
-    int32_t es = 0;
-    return run_align<4, false>(e, p, a, n, b, m, maxscore, &es, ops, fi, fj);
+    HostJob j; j.a = a; j.n = n; j.b = b; j.m = m;
+    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 64;
+    const int rc = run_group<4, false>(e, p, &j, 1, T);
+    *maxscore = j.maxscore;
+    return rc;
+}
+
+// the two gapped rows of one pair from its walker ops (psa.c:464-516: leftover prefix of a against gaps, leftover
+// prefix of b against gaps, then reverse); malloc'd, NUL-terminated
+static int assemble_rows(Engine* e, const HostJob& J, char** row_a, char** row_b, int64_t* out_len)
+{
+    const uint8_t* a = J.a; const uint8_t* b = J.b;
+    const int64_t len = (int64_t)J.ops.size() + J.fi + J.fj;
+    char* ra = (char*)malloc((size_t)len + 1);
+    char* rb = (char*)malloc((size_t)len + 1);
+    if (!ra || !rb) { free(ra); free(rb); return TSTA_ERR_OOM; }
+    ra[len] = rb[len] = '\0';
+    int64_t q = len;
+    int i = J.m, j = J.n;
+    for (size_t x = 0; x < J.ops.size(); ++x) {
+        const int k = J.ops[x];
+        if (k == 1)      { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = (char)b[i - 1]; --i; --j; }
+        else if (k == 0) { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = '-'; --j; }
+        else             { ra[q - 1] = '-'; rb[q - 1] = (char)b[i - 1]; --i; }
+        --q;
+    }
+    if (i != J.fi || j != J.fj) { free(ra); free(rb); e->set_error("walker/ops mismatch"); return TSTA_ERR_INTERNAL; }
+    while (j >= 1) { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = '-'; --j; --q; }
+    while (i >= 1) { rb[q - 1] = (char)b[i - 1]; ra[q - 1] = '-'; --i; --q; }
+    *row_a = ra; *row_b = rb; *out_len = len;
+    return TSTA_OK;
 }
 
 }  // namespace tsta
@@ -434,38 +541,101 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
     if (rc != TSTA_OK) return rc;
     // psa.c:194-199: the strictly longer input becomes seq[0] = columns = ">1"
     const bool swap = l2 > l1;
-    const uint8_t* a = swap ? s2 : s1; const int n = (int)(swap ? l2 : l1);
-    const uint8_t* b = swap ? s1 : s2; const int m = (int)(swap ? l1 : l2);
-
-    std::vector<uint8_t> ops;
-    int fi = m, fj = n;
-    int32_t ms = -100, es = 0;
-    if (m > 0 && n > 0) {
+    HostJob J;
+    J.a = swap ? s2 : s1; J.n = (int)(swap ? l2 : l1);
+    J.b = swap ? s1 : s2; J.m = (int)(swap ? l1 : l2);
+    J.fi = J.m; J.fj = J.n;
+    if (J.m > 0 && J.n > 0) {
         // rows per lane: small bands expose more concurrent bands of the single pair
         const int R_env = e->opt_trace_rows;                                                    // knob "trace_rows"
         const int Rsel = (R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
-        if (Rsel == 4) rc = run_align<4, true>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
-        else           rc = run_align<2, true>(e, p, a, n, b, m, &ms, &es, ops, fi, fj);
+        const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 64;   // knob "trace_tile"
+        if (Rsel == 4) rc = run_group<4, true>(e, p, &J, 1, T);
+        else           rc = run_group<2, true>(e, p, &J, 1, T);
         if (rc != TSTA_OK) return rc;
     }
-    // psa.c:464-516: leftover prefix of a against gaps, leftover prefix of b against gaps, then reverse
-    const int64_t len = (int64_t)ops.size() + fi + fj;
-    char* ra = (char*)malloc((size_t)len + 1);
-    char* rb = (char*)malloc((size_t)len + 1);
-    if (!ra || !rb) { free(ra); free(rb); return TSTA_ERR_OOM; }
-    ra[len] = rb[len] = '\0';
-    int64_t q = len;
-    int i = m, j = n;
-    for (size_t x = 0; x < ops.size(); ++x) {
-        const int k = ops[x];
-        if (k == 1)      { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = (char)b[i - 1]; --i; --j; }
-        else if (k == 0) { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = '-'; --j; }
-        else             { ra[q - 1] = '-'; rb[q - 1] = (char)b[i - 1]; --i; }
-        --q;
-    }
-    if (i != fi || j != fj) { free(ra); free(rb); e->set_error("walker/ops mismatch"); return TSTA_ERR_INTERNAL; }
-    while (j >= 1) { ra[q - 1] = (char)a[j - 1]; rb[q - 1] = '-'; --j; --q; }
-    while (i >= 1) { rb[q - 1] = (char)b[i - 1]; ra[q - 1] = '-'; --i; --q; }
-    *maxscore = ms; *row_a = ra; *row_b = rb; *out_len = len;
+    if ((rc = assemble_rows(e, J, row_a, row_b, out_len)) != TSTA_OK) return rc;
+    *maxscore = J.maxscore;
     return TSTA_OK;
+}
+
+extern "C" void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs)
+{
+    if (!out) return;
+    for (int64_t k = 0; k < n_pairs; ++k) { free(out[k].row_a); free(out[k].row_b); out[k].row_a = out[k].row_b = nullptr; }
+}
+
+extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                                    int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                                    const int64_t* off2, const int32_t* len2, tsta_alignment* out)
+{
+    using namespace tsta;
+    if (!eng || !p || n_pairs < 0) return TSTA_ERR_INVALID_ARG;
+    if (n_pairs == 0) return TSTA_OK;
+    if (!off1 || !len1 || !off2 || !len2 || !out || seqs_bytes < 0 || (seqs_bytes && !seqs)) return TSTA_ERR_INVALID_ARG;
+    if (n_pairs > (1 << 24)) return TSTA_ERR_UNSUPPORTED;
+    for (int64_t k = 0; k < n_pairs; ++k) {
+        if (len1[k] < 0 || len2[k] < 0 || off1[k] < 0 || off2[k] < 0 || off1[k] + len1[k] > seqs_bytes || off2[k] + len2[k] > seqs_bytes)
+            return TSTA_ERR_INVALID_ARG;
+        if (len1[k] > (1 << 24) || len2[k] > (1 << 24)) return TSTA_ERR_UNSUPPORTED;
+    }
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
+    if (rc != TSTA_OK) return rc;
+    for (int64_t k = 0; k < n_pairs; ++k) { out[k].maxscore = -100; out[k].len = 0; out[k].row_a = out[k].row_b = nullptr; }
+
+    std::vector<HostJob> jobs((size_t)n_pairs);
+    int64_t bands4 = 0;
+    for (int64_t k = 0; k < n_pairs; ++k) {
+        const bool swap = len2[k] > len1[k];                       // psa.c:194-199
+        HostJob& J = jobs[(size_t)k];
+        J.a = seqs + (swap ? off2[k] : off1[k]); J.n = swap ? len2[k] : len1[k];
+        J.b = seqs + (swap ? off1[k] : off2[k]); J.m = swap ? len1[k] : len2[k];
+        J.fi = J.m; J.fj = J.n;
+        bands4 += (J.m + 255) / 256;
+    }
+    // rows per lane / tile length: with enough bands in flight to fill every SIMD several times over, taller bands and
+    // longer tiles cost fewer instructions per cell; a few long pairs want many short bands instead (see tsta_psa_align)
+    const int R_env = e->opt_trace_rows;
+    const int Rsel = (R_env == 2 || R_env == 4) ? R_env : (bands4 >= (int64_t)e->n_cu * 16 ? 4 : 2);
+    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : (bands4 >= (int64_t)e->n_cu * 16 ? 256 : 64);
+    // groups of pairs whose workspaces (1 B per DP cell of trace, mostly) fit the device together
+    size_t free_b = 0, total_b = 0;
+    if ((rc = e->check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo")) != TSTA_OK) return rc;
+    const size_t held = e->in_seqs.bytes + e->rows.bytes + e->scratch.bytes + e->trace.bytes + e->scratch2.bytes + e->in_meta.bytes;
+    size_t budget = (size_t)((double)(free_b + held) * 0.85);
+    if (const char* v = getenv("TSTA_ALIGN_BUDGET_MB")) budget = std::min(budget, (size_t)atoll(v) << 20);
+    auto job_bytes = [&](const HostJob& J) { return Rsel == 4 ? JobGeom<4>(J.n, J.m, true).total() : JobGeom<2>(J.n, J.m, true).total(); };
+    std::vector<HostJob> group;
+    std::vector<int64_t> group_idx;
+    size_t used = 0;
+    auto flush = [&]() -> int {
+        if (group.empty()) return TSTA_OK;
+        int r = Rsel == 4 ? run_group<4, true>(e, p, group.data(), (int)group.size(), T)
+                          : run_group<2, true>(e, p, group.data(), (int)group.size(), T);
+        if (r != TSTA_OK) return r;
+        for (size_t x = 0; x < group.size(); ++x) {
+            tsta_alignment& o = out[group_idx[x]];
+            if ((r = assemble_rows(e, group[x], &o.row_a, &o.row_b, &o.len)) != TSTA_OK) return r;
+            o.maxscore = group[x].maxscore;
+        }
+        group.clear(); group_idx.clear(); used = 0;
+        return TSTA_OK;
+    };
+    for (int64_t k = 0; k < n_pairs && rc == TSTA_OK; ++k) {
+        HostJob& J = jobs[(size_t)k];
+        if (J.m == 0 || J.n == 0) {                       // nothing to fill: one sequence against gaps
+            tsta_alignment& o = out[k];
+            rc = assemble_rows(e, J, &o.row_a, &o.row_b, &o.len);
+            continue;
+        }
+        const size_t need = job_bytes(J);
+        if (need > budget) { e->set_error("pair %lld needs %zu bytes of device workspace, %zu available", (long long)k, need, budget); rc = TSTA_ERR_OOM; break; }
+        if (used + need > budget || group.size() >= 65535) rc = flush();
+        if (rc != TSTA_OK) break;
+        group.push_back(J); group_idx.push_back(k); used += need;
+    }
+    if (rc == TSTA_OK) rc = flush();
+    if (rc != TSTA_OK) tsta_alignments_free(out, n_pairs);
+    return rc;
 }
