@@ -56,6 +56,31 @@ def config3(eng):
             "trace_write_GBs": cells / (k2 * 1e-3) / 1e9}
 
 
+def config5t(eng, n_pairs=64, L=50_000):
+    """Not a BASELINE config: the config #5 pair shape WITH traceback, as many pairs as fit the device in one group."""
+    pairs = []
+    for i in range(n_pairs):
+        a = util.random_dna(5000 + i, L)
+        pairs.append((a, util.mutate(a, 6000 + i, 0.05)[:L]))
+    eng.psa_align_batch(pairs[:2])                              # warm-up
+    t0 = time.perf_counter()
+    res = eng.psa_align_batch(pairs)
+    wall = time.perf_counter() - t0
+    k, nl = eng.last_kernel_ms()
+    cells = float(sum(len(a) * len(b) for a, b in pairs))
+    t0 = time.perf_counter()
+    res2 = eng.psa_align_batch(pairs)
+    wall2 = time.perf_counter() - t0
+    k2, _ = eng.last_kernel_ms()
+    assert res == res2
+    one = eng.psa_align(*pairs[0])
+    assert one == res[0]
+    return {"config": "#5 shape with traceback: %d pairs of %d x ~%d in one group (1 B/cell packed trace in HBM)" % (n_pairs, L, L),
+            "kernel_ms_first": k, "kernel_ms": k2, "launches": nl, "wall_ms_first": wall * 1e3, "wall_ms": wall2 * 1e3,
+            "gcups_kernel": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e9, "trace_bytes": cells,
+            "trace_write_GBs": cells / (k2 * 1e-3) / 1e9, "hbm_write_frac_of_8TBs": cells / (k2 * 1e-3) / 8e12}
+
+
 def config4(eng):
     out = []
     tot_cells, tot_k, tot_wall = 0.0, 0.0, 0.0
@@ -89,6 +114,8 @@ if __name__ == "__main__":
         print(json.dumps(config2(eng)), flush=True)
     if "3" in which:
         print(json.dumps(config3(eng)), flush=True)
+    if "5t" in which:
+        print(json.dumps(config5t(eng, int(os.environ.get("TSTA_BENCH_ALIGN_PAIRS", 64)))), flush=True)
     if "4" in which:
         print(json.dumps(config4(eng)), flush=True)
     eng.close()

@@ -66,6 +66,9 @@ template <int R> struct TraceCfg {
     static constexpr int NS = 2 * R + 5;        // state ints per lane
 };
 
+// sign(x) in {-1, 0, 1}: one v_med3_i32 (the compiler expands min(max(x,-1),1) into compares and selects)
+__device__ __forceinline__ int sign3(int x) { int r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x)); return r; }
+
 __device__ __forceinline__ int hcol0t(int i, int E, int O) { return i == 0 ? 0 : O + i * E; }
 
 template <int R>
@@ -75,26 +78,26 @@ struct TLane {
     int th, te, ach, sh, se;
 };
 
-// one DP step of the lane's R rows; returns the R trace bytes packed little-endian into `tb` (R<=4: one dword,
-// R==8: two dwords)
+// one DP step of the lane's R rows; ADDS the R trace bytes, little-endian and each short of its +0x14 (see below),
+// into `tb` (R<=4: one dword, R==8: two dwords).
+// Trace byte = nd | nf<<1 | (fge+1)<<2 | (ege+1)<<4 with fge, ege in {-1,0,1} = (nd + 2nf + 4fge + 16ege) + 20: the
+// bracket is built with three v_lshl_add_u32 (it may be negative), shifted into its byte with a fourth, and the +20
+// of all four bytes of a dword is added once (0x14141414) by the caller — integer arithmetic is linear, borrows
+// between bytes cancel.
 template <int R, bool PRED, bool TRACE>
 __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int lane, const int n, const int nvalid,
-                                           const int M, const int X, const int E, const int O, unsigned (&tb)[(R + 3) / 4])
+                                           const int M, const int X, const int E, const int O, int (&tb)[(R + 3) / 4])
 {
-    s.cch = wave_shr1(s.ach, s.cch);
-    const int hu = wave_shr1(s.th, s.hbot);
-    int eu = wave_shr1(s.te, s.ebot);
-    s.sh = wave_shl1(s.hbot, s.sh);
-    s.se = wave_shl1(s.ebot, s.se);
-    s.th = wave_shl1(s.th, s.th);
-    s.te = wave_shl1(s.te, s.te);
-    s.ach = wave_shl1(s.ach, s.ach);
+    unsigned hu_u, eu_u;
+    lane_exchange(reinterpret_cast<unsigned&>(s.cch), hu_u, eu_u, reinterpret_cast<unsigned&>(s.sh), reinterpret_cast<unsigned&>(s.se),
+                  reinterpret_cast<unsigned&>(s.ach), reinterpret_cast<unsigned&>(s.th), reinterpret_cast<unsigned&>(s.te),
+                  (unsigned)s.hbot, (unsigned)s.ebot);
+    const int hu = (int)hu_u;
+    int eu = (int)eu_u;
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     int d = s.hd;
     int h = 0;
-#pragma unroll
-    for (int q = 0; q < (R + 3) / 4; ++q) tb[q] = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int e = eu + E;
@@ -102,13 +105,13 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
         const int dg = d + (s.cch == s.bch[k] ? M : X);
         h = max3i(dg, e, f);
         const int g = h + O;
-        if (TRACE) {                                        // trace code (see file header)
+        if (TRACE) {
             const int nd = min(h - dg, 1);
             const int nf = min(h - f, 1);
-            const int fge = min(max(g - f, -1), 1) + 1;
-            const int ege = min(max(g - e, -1), 1) + 1;
-            const unsigned code = (unsigned)(nd | (nf << 1) | (fge << 2) | (ege << 4));
-            tb[k / 4] |= code << (8 * (k % 4));
+            const int fge = sign3(g - f);       // sign(H+O-F)
+            const int ege = sign3(g - e);       // sign(H+O-E)
+            const int code = (ege << 4) + ((fge << 2) + ((nf << 1) + nd));
+            tb[k / 4] = (code << (8 * (k % 4))) + tb[k / 4];
         }
         const int eb = max(e, g);
         const int fbn = max(f, g);
@@ -138,17 +141,20 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
     // tq -> trace group of step t0 for this lane (stride 64 uint4 per group)
 #pragma unroll 1
     for (int g = 0; g < 64 / SPB; ++g) {
-        unsigned acc[4] = {0u, 0u, 0u, 0u};
+        int acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < SPB; ++q) {
-            unsigned tb[(R + 3) / 4];
+            int tb[(R + 3) / 4];
+#pragma unroll
+            for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
             trace_step<R, PRED, TRACE>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
             if constexpr (!TRACE) { (void)acc; }
             else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
-            else { acc[(q * R) / 4] |= tb[0] << (8 * ((q * R) % 4)); }
+            else { acc[(q * R) / 4] = (tb[0] << (8 * ((q * R) % 4))) + acc[(q * R) / 4]; }
         }
-        if (TRACE) tq[(size_t)g * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        if (TRACE) tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
+                                                   (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
     }
 }
 
