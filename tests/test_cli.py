@@ -96,3 +96,13 @@ def test_batch_cli(built, tmp_path):
     assert r.returncode == 0, r.stderr
     want = util.oracle_maxscore_batch(pairs)
     assert r.stdout == b"".join(b"maxsorce=%d\n" % w for w in want)
+    # with -o: every pair aligned with traceback in one tsta_psa_align_batch call; per pair the bytes TSTA_psa writes
+    out = tmp_path / "alignments.txt"
+    r = run([os.path.join(built, "TSTA_psa_batch"), "-1", str(fa), "-2", str(fb), "-o", str(out)])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == b"".join(b"maxsorce=%d\n" % w for w in want)
+    expect = b""
+    for a, b in pairs:
+        ms, end, ra, rb = util.oracle_align(a, b)
+        expect += b">1\n" + ra + b"\n>2\n" + rb + b"\n"
+    assert out.read_bytes() == expect

@@ -2,7 +2,10 @@
  * multi-FASTA against record k of the -2 multi-FASTA, all pairs in ONE tsta_psa_score_batch call (packed kernel,
  * pairs ordered by geometry on the device).  Same scoring flags as TSTA_psa_notrace; prints one line per pair,
  * "maxsorce=%d" exactly as the reference prints it for a single pair (psa.c:666).
- *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O]        env TSTA_DEVICE = GPU index */
+ * With -o <file>: every pair is aligned WITH traceback (tsta_psa_align_batch, the pairs' fills in flight together)
+ * and <file> receives, per pair, exactly the bytes TSTA_psa writes to its output file (">1\n" row ">\n>2\n" row,
+ * psa.c:512-516) followed by one "\n" as record separator.
+ *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O] [-o alignments.txt]        env TSTA_DEVICE = GPU index */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,9 +17,9 @@
 int main(int argc, char* argv[])
 {
     tsta_params prm = {2, -5, -2, -4};
-    const char *input1 = NULL, *input2 = NULL;
+    const char *input1 = NULL, *input2 = NULL, *output = NULL;
     int c;
-    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:")) != -1) {
+    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:o:")) != -1) {
         switch (c) {
             case 'M': prm.M = atoi(optarg); break;
             case 'X': prm.X = atoi(optarg); break;
@@ -25,10 +28,11 @@ int main(int argc, char* argv[])
             case 'T': case 'W': break;
             case '1': input1 = optarg; break;
             case '2': input2 = optarg; break;
-            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4]\n"); return 2;
+            case 'o': output = optarg; break;
+            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-o alignments.txt]\n"); return 2;
         }
     }
-    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4]\n"); return 2; }
+    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-o alignments.txt]\n"); return 2; }
     fasta_file* f1 = fasta_read(input1, 0);
     fasta_file* f2 = fasta_read(input2, 0);
     if (f1->count != f2->count) { fprintf(stderr, "record counts differ: %zu vs %zu\n", f1->count, f2->count); return 1; }
@@ -48,8 +52,25 @@ int main(int argc, char* argv[])
     tsta_engine* eng = NULL;
     int rc = tsta_engine_create(dev ? atoi(dev) : 0, &eng);
     if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
-    rc = tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
-    if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+    if (output) {
+        tsta_alignment* al = (tsta_alignment*)calloc(n ? n : 1, sizeof(tsta_alignment));
+        FILE* fo = fopen(output, "w");
+        if (!fo) { fprintf(stderr, "cannot open %s\n", output); return 1; }
+        rc = tsta_psa_align_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, al);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_align_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+        for (size_t k = 0; k < n; k++) {
+            fputs(">1\n", fo); fwrite(al[k].row_a, 1, (size_t)al[k].len, fo);
+            fputs("\n>2\n", fo); fwrite(al[k].row_b, 1, (size_t)al[k].len, fo);
+            fputc('\n', fo);
+            out[k] = al[k].maxscore;
+        }
+        fclose(fo);
+        tsta_alignments_free(al, (int64_t)n);
+        free(al);
+    } else {
+        rc = tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+    }
     for (size_t k = 0; k < n; k++) printf("maxsorce=%d\n", out[k]);
     tsta_engine_destroy(eng);
     fasta_free(f1); fasta_free(f2);
