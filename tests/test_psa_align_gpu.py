@@ -211,3 +211,43 @@ def test_batch_full_size_50k_properties(eng):
         assert ms == oms and util.alignment_score(ra, rb) == oend
     one = eng.psa_align(*cases[0])
     assert one == res[0]
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=4, X=-6, E=-3, O=-5),
+                                     dict(M=10, X=-10, E=-3, O=-12),       # too wide for 16-bit lanes at R=4: stays on K2
+                                     dict(M=2, X=3, E=-2, O=-4)])          # X > M: stays on K2
+def test_batch_packed_trace_fill(eng, scoring):
+    # K2p (psa_trace_packed.hip): jobs of similar geometry are filled two per wave in packed 16-bit lanes; trace bytes,
+    # walk and output must be identical to K2's.  Equal sizes, unequal couples, an odd job out, a non-ACGT byte,
+    # identical / unrelated / low-complexity content, sizes around the band (256 rows) and block (64 columns) edges.
+    rng = np.random.default_rng(91)
+    cases = []
+    for (n, m) in [(256, 256), (257, 255), (64, 64), (1, 1), (700, 300), (700, 290), (1300, 1290), (1290, 1300),
+                   (2049, 2047), (2049, 2040), (3000, 512), (3000, 500), (5000, 4100), (4900, 4000), (777, 5)]:
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = len(cases) % 4
+        if kind == 0:
+            b = util.mutate(a, int(rng.integers(1 << 30)), 0.08)[:m]
+        elif kind == 1:
+            b = util.random_dna(int(rng.integers(1 << 30)), m)
+        elif kind == 2:
+            b = a[:m].copy()
+        else:
+            b = util.low_complexity(int(rng.integers(1 << 30)), m, 2)
+        if len(b) < m:
+            b = np.concatenate([b, util.random_dna(5, m - len(b))])
+        cases.append((a, b) if len(cases) % 3 else (b, a))
+    xn = cases[4][0].copy(); xn[100] = ord("N")
+    cases.append((xn, cases[4][1]))
+    want = [util.oracle_align(s1, s2, **scoring) for s1, s2 in cases]
+    try:
+        eng.set_option("trace_rows", 4)
+        for packed in (1, 0):
+            eng.set_option("trace_packed", packed)
+            for tile in (64, 256):
+                eng.set_option("trace_tile", tile)
+                res = eng.psa_align_batch(cases, tsta_amd.Params(**scoring))
+                for w, got, (s1, s2) in zip(want, res, cases):
+                    assert got == (w[0], w[2], w[3]), (packed, tile, len(s1), len(s2), scoring)
+    finally:
+        eng.set_option("trace_rows", 0); eng.set_option("trace_packed", 1); eng.set_option("trace_tile", 0)

@@ -39,6 +39,16 @@ __host__ __device__ inline bool psa_couple_is_packed(const int32_t* len1, const 
     return 5 * pn * pm <= 4 * (na * ma + nb * mb);
 }
 
+// how far (in score units) any value in flight can stray from a pair's anchor in the packed 16-bit kernels with
+// rows-per-lane R: rows 64R + columns <= 192 (drain block), U per step, +M per column of the shifted frame.  Must stay
+// below 28000 (u16 window around the bias).
+inline int64_t psa_packed_window(int64_t M, int64_t X, int64_t E, int64_t O, int R)
+{
+    const int64_t mx = M > X ? M : X;
+    const int64_t U = (mx > 0 ? mx : 0) - O - E;
+    return (64LL * R + 256) * U - 2LL * O - E + 200LL * M;
+}
+
 struct PsaPackedArgs {
     PsaBatchArgs b;                 // same batch description; b.counter -> this kernel's own ticket word
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves

@@ -28,18 +28,12 @@ static int psa_rows_per_lane(int32_t max_len, int forced)
 // does not fit: the kernel needs E,O <= 0 <= M, 0 <= M-X <= 255 and every value in flight within the 16-bit
 // window around the per-pair base: (64R+256)*U + |O+E| + |O| + 200*M < 28000, U = max(M,X,0)+|O|+|E| bounding the
 // score difference of adjacent cells.
-static int64_t psa_packed_window(const tsta_params& p, int R)
-{
-    const int64_t U = std::max(std::max(p.M, p.X), 0) - (int64_t)p.O - (int64_t)p.E;
-    return (64LL * R + 256) * U - 2LL * p.O - p.E + 200LL * p.M;   // rows 64R + columns <= 192 (drain block) from the anchor; +M per column of the shifted frame
-}
-
 static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int mode, int32_t max_len)   // mode: -1 auto, 0 never, 8/16/32 forced
 {
     if (mode == 0 || couples < 1) return 0;
     if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
     if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
-    auto fits = [&](int R) { return psa_packed_window(p, R) < 28000; };
+    auto fits = [&](int R) { return psa_packed_window(p.M, p.X, p.E, p.O, R) < 28000; };
     if (mode == 32) return fits(32) ? 32 : (fits(16) ? 16 : (fits(8) ? 8 : 0));
     if (mode == 16) return fits(16) ? 16 : (fits(8) ? 8 : 0);
     if (mode == 8) return fits(8) ? 8 : 0;
@@ -188,7 +182,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         pa.pe = ae | (ae << 16); pa.po = ao | (ao << 16); pa.pm = am | (am << 16); pa.pmx = amx | (amx << 16);
         // the frame of the elided blocks spreads the rows of a band by |E| each: needs that much more of the 16-bit window
-        pa.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(*p, Rp) + (int64_t)ae * (32 * (Rp + 1) + 192) < 28000;
+        pa.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rp) + (int64_t)ae * (32 * (Rp + 1) + 192) < 28000;
         pa.acgt = acgt;
         if (acgt) {
             hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,

@@ -18,25 +18,9 @@
 #include <stdint.h>
 #include "kernels.h"
 #include "wave_ops.h"
+#include "packed_ops.h"
 
 namespace tsta {
-
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-}
-__device__ __forceinline__ unsigned pkmin(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-}
-__device__ __forceinline__ unsigned pksub(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
-}
-__device__ __forceinline__ unsigned pkadd(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
-}
-__device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
-__device__ __forceinline__ unsigned ushr1(unsigned old, unsigned src) { return (unsigned)wave_shr1((int)old, (int)src); }
-__device__ __forceinline__ unsigned ushl1(unsigned old, unsigned src) { return (unsigned)wave_shl1((int)old, (int)src); }
 
 // 0 / M-X per half for (column character, row character):
 //   generic bytes:  min_u16((a ^ b) << 8, M-X)                                              (2 VALU)
@@ -54,8 +38,6 @@ __device__ __forceinline__ unsigned acgt_code(int c) { return ((unsigned)c >> 1)
 // the column's table for one pair: M-X in the four bytes, 0 at the column's own code
 __device__ __forceinline__ unsigned acgt_table(int c, unsigned k4) { return k4 & ~(0xffu << (8 * acgt_code(c))); }
 
-constexpr int kBias = 0x8000;
-constexpr int kNegInfP = -(1 << 30);
 
 template <int R>
 struct PLane {
@@ -176,21 +158,9 @@ __device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const in
     { const int v = sign * ae * (lane_part + R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
 }
 
-__device__ __forceinline__ int hcol0p(int i, int E, int O) { return i == 0 ? 0 : O + i * E; }
-
-struct PairAcc { int baseA, baseB, mxA, mxB, ancA, ancB; };   // base: anchor of the H' frame; anc: anchor of the running max (H frame)
-
 template <int R>
-__device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc)
-{
-    if ((s.mx & 0xffffu) != 0u) acc.mxA = max(acc.mxA, (int)(s.mx & 0xffffu) + acc.ancA - kBias);
-    if ((s.mx >> 16) != 0u)     acc.mxB = max(acc.mxB, (int)(s.mx >> 16) + acc.ancB - kBias);
-    s.mx = 0u;
-}
+__device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx(s.mx, acc); }
 
-// VALU instructions with an SGPR source issue in the slow class on gfx950 (tools/valu_microbench.hip: v_sub_u32
-// 1.1 -> 2.0+ cycles), so the four packed constants are pinned in VGPRs.
-__device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "s"(x)); return x; }
 
 // The two pairs of a couple may differ in size: the wave sweeps max(nA,nB) columns and max(mA,mB) rows; cells
 // outside the smaller pair compute garbage that only feeds other such cells and is masked out of its running max.

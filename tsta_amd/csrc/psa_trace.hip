@@ -34,37 +34,12 @@
 #include "../../include/tsta_engine.h"
 #include "engine.h"
 #include "wave_ops.h"
+#include "trace_types.h"
+#include "kernels.h"
 
 namespace tsta {
 
 constexpr int kNegInfT = -(1 << 30);
-
-// one oriented pair (a = columns = longer sequence, b = rows) of a group, device-resident
-struct TraceJob {
-    const uint8_t* a; const uint8_t* b;
-    int n, m;
-    int2*     rows;                 // [W+1][row_stride]: rows[w] = top row of band w ({H, Ebar} per column)
-    int64_t   row_stride;
-    int*      state;                // [W][NS][64] per-lane DP state between tiles
-    uint8_t*  trace;                // [W][band_bytes]
-    int64_t   band_bytes;
-    int       W, S_total;           // bands, total steps per band (multiple of 64)
-    int       band0;                // index of this job's first band among the bands of the group
-    uint8_t*  ops;                  // walker output (see WalkArgs)
-    int*      out;                  // [8]: maxsorce, H(m,n), #ops, final i, final j
-};
-
-struct PsaTraceArgs {
-    const TraceJob* jobs; int n_jobs;
-    int g_lo, g_hi;                 // range of group-wide band indices this launch covers
-    int T, d;                       // tile length (steps), launch index
-    int M, X, E, O;
-};
-
-template <int R> struct TraceCfg {
-    static constexpr int SPB = 16 / R;          // steps per 16-byte trace group
-    static constexpr int NS = 2 * R + 5;        // state ints per lane
-};
 
 // sign(x) in {-1, 0, 1}: one v_med3_i32 (the compiler expands min(max(x,-1),1) into compares and selects)
 __device__ __forceinline__ int sign3(int x) { int r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x)); return r; }
@@ -381,12 +356,13 @@ struct HostJob {
     int fi = 0, fj = 0;             // cell at which the walk stopped
 };
 
+// layout of one job's workspaces for a sweep of n_lay columns x m_lay rows (its own size, or its couple's)
 template <int R> struct JobGeom {
     int W, S_total; int64_t row_stride, band_bytes;
     size_t rows_bytes, state_bytes, trace_bytes, ops_bytes, seq_bytes;
-    JobGeom(int n, int m, bool trace) {
-        W = (m + 64 * R - 1) / (64 * R);
-        S_total = (n + 64 + 63) / 64 * 64;
+    JobGeom(int n, int m, int n_lay, int m_lay, bool trace) {
+        W = (m_lay + 64 * R - 1) / (64 * R);
+        S_total = (n_lay + 64 + 63) / 64 * 64;
         row_stride = S_total + 64;
         band_bytes = (int64_t)S_total * 64 * R;
         rows_bytes = (size_t)(W + 1) * row_stride * sizeof(int2);
@@ -395,30 +371,71 @@ template <int R> struct JobGeom {
         ops_bytes = trace ? ((size_t)n + m + 64 + 63) / 64 * 64 : 0;
         seq_bytes = ((size_t)n + m + 64 + 63) / 64 * 64;
     }
+    JobGeom(int n, int m, bool trace) : JobGeom(n, m, n, m, trace) {}
     size_t total() const { return rows_bytes + state_bytes + trace_bytes + ops_bytes + seq_bytes + 256; }
 };
+
+// can the packed 16-bit trace fill (psa_trace_packed.hip) take this scoring?  (same domain as K1p at R = kPackedTraceR)
+static bool packed_trace_fits(const tsta_params& p)
+{
+    if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return false;
+    if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return false;
+    return psa_packed_window(p.M, p.X, p.E, p.O, kPackedTraceR) < 28000;
+}
 
 // TRACE = true: fill with packed trace + on-device walk of every job of the group.  TRACE = false: the same pipelined
 // fill, score only (psa_score_single_pair: a single long pair would otherwise occupy one wave of the batch kernel).
 // All jobs of the group are in flight together: launch d advances every band of every job by one T-step tile.
+// With R = kPackedTraceR and a scoring that fits 16-bit lanes, jobs of similar geometry are coupled and filled two per
+// wave by K2p (psa_trace_packed.hip); the rest ("singles") by K2.
 template <int R, bool TRACE>
 static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs, int T)
 {
+    constexpr int NSP = 2 * kPackedTraceR + 8;
     hipStream_t s = e->stream;
+    // ---- couples: adjacent jobs in geometry order whose padded sweep stays below 1.25x their own cells
+    std::vector<int> lay_n((size_t)n_jobs), lay_m((size_t)n_jobs), couple_of((size_t)n_jobs, -1);
+    for (int j = 0; j < n_jobs; ++j) { lay_n[j] = jobs[j].n; lay_m[j] = jobs[j].m; }
+    std::vector<TraceCouple> tc;
+    if (TRACE && R == kPackedTraceR && n_jobs >= 2 && e->opt_trace_packed != 0 && packed_trace_fits(*p)) {
+        std::vector<int> order((size_t)n_jobs);
+        for (int j = 0; j < n_jobs; ++j) order[j] = j;
+        std::sort(order.begin(), order.end(), [&](int x, int y) {
+            if (jobs[x].n != jobs[y].n) return jobs[x].n > jobs[y].n;
+            if (jobs[x].m != jobs[y].m) return jobs[x].m > jobs[y].m;
+            return x < y;
+        });
+        for (int q = 0; q + 1 < n_jobs; ++q) {
+            const int x = order[q], y = order[q + 1];
+            const int64_t pn = std::max(jobs[x].n, jobs[y].n), pm = std::max(jobs[x].m, jobs[y].m);
+            if (5 * pn * pm > 4 * ((int64_t)jobs[x].n * jobs[x].m + (int64_t)jobs[y].n * jobs[y].m)) continue;
+            TraceCouple c; c.ja = x; c.jb = y; c.band0 = 0; c.W = 0; c.S_total = 0; c.state = nullptr;
+            couple_of[x] = couple_of[y] = (int)tc.size();
+            lay_n[x] = lay_n[y] = (int)pn; lay_m[x] = lay_m[y] = (int)pm;
+            tc.push_back(c);
+            ++q;
+        }
+    }
+    const int n_couples = (int)tc.size();
+
     std::vector<TraceJob> tj((size_t)n_jobs);
     size_t rows_b = 0, state_b = 0, trace_b = 0, ops_b = 0, seq_b = 0;
-    int64_t total_bands = 0;
+    int64_t single_bands = 0, couple_bands = 0;
+    int n_singles = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        const JobGeom<R> g(jobs[j].n, jobs[j].m, TRACE);
-        rows_b += g.rows_bytes; state_b += g.state_bytes; trace_b += g.trace_bytes; ops_b += g.ops_bytes; seq_b += g.seq_bytes;
-        total_bands += g.W;
+        const JobGeom<R> g(jobs[j].n, jobs[j].m, lay_n[j], lay_m[j], TRACE);
+        rows_b += g.rows_bytes; trace_b += g.trace_bytes; ops_b += g.ops_bytes; seq_b += g.seq_bytes;
+        if (couple_of[j] < 0) { state_b += g.state_bytes; single_bands += g.W; ++n_singles; }
+        else if (tc[couple_of[j]].ja == j) { state_b += (size_t)g.W * NSP * 64 * sizeof(int); couple_bands += g.W; }
     }
-    if (total_bands > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
+    if (single_bands > 0x7fffffff || couple_bands > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
+    const size_t jobs_b = ((size_t)(n_jobs + n_singles) * sizeof(TraceJob) + 255) / 256 * 256;
+    const size_t couples_b = ((size_t)n_couples * sizeof(TraceCouple) + 255) / 256 * 256;
     int rc;
     if ((rc = e->reserve(e->in_seqs, seq_b, "hipMalloc(seqs)")) ||
         (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
-        (rc = e->reserve(e->scratch, state_b, "hipMalloc(state)")) ||
-        (rc = e->reserve(e->in_meta, (size_t)n_jobs * (sizeof(TraceJob) + 8 * sizeof(int)) + 256, "hipMalloc(jobs)")) ||
+        (rc = e->reserve(e->scratch, state_b + 256, "hipMalloc(state)")) ||
+        (rc = e->reserve(e->in_meta, jobs_b + couples_b + (size_t)n_jobs * 8 * sizeof(int) + 256, "hipMalloc(jobs)")) ||
         (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
         (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
@@ -427,29 +444,53 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     char* d_state = reinterpret_cast<char*>(e->scratch.p);
     char* d_trace = reinterpret_cast<char*>(e->trace.p);
     char* d_ops = reinterpret_cast<char*>(e->scratch2.p);
-    TraceJob* d_jobs = reinterpret_cast<TraceJob*>(e->in_meta.p);
-    int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + ((size_t)n_jobs * sizeof(TraceJob) + 255) / 256 * 256);
-    int band0 = 0, max_n = 0;
+    TraceJob* d_jobs = reinterpret_cast<TraceJob*>(e->in_meta.p);            // all jobs, then the singles again
+    TraceJob* d_singles = d_jobs + n_jobs;
+    TraceCouple* d_couples = reinterpret_cast<TraceCouple*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b);
+    int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b + couples_b);
+    int sband0 = 0, cband0 = 0, max_n = 0;
+    std::vector<TraceJob> singles;
     for (int j = 0; j < n_jobs; ++j) {
-        const JobGeom<R> g(jobs[j].n, jobs[j].m, TRACE);
+        const JobGeom<R> g(jobs[j].n, jobs[j].m, lay_n[j], lay_m[j], TRACE);
         TraceJob& J = tj[j];
         J.a = reinterpret_cast<const uint8_t*>(d_seq); J.b = J.a + jobs[j].n; J.n = jobs[j].n; J.m = jobs[j].m;
         if ((rc = e->check(hipMemcpyAsync(d_seq, jobs[j].a, jobs[j].n, hipMemcpyHostToDevice, s), "H2D a")) ||
             (rc = e->check(hipMemcpyAsync(d_seq + jobs[j].n, jobs[j].b, jobs[j].m, hipMemcpyHostToDevice, s), "H2D b")))
             return rc;
         J.rows = reinterpret_cast<int2*>(d_rows); J.row_stride = g.row_stride;
-        J.state = reinterpret_cast<int*>(d_state);
         J.trace = reinterpret_cast<uint8_t*>(d_trace); J.band_bytes = g.band_bytes;
-        J.W = g.W; J.S_total = g.S_total; J.band0 = band0;
+        J.W = g.W; J.S_total = g.S_total;
         J.ops = reinterpret_cast<uint8_t*>(d_ops); J.out = d_out + 8 * j;
-        d_seq += g.seq_bytes; d_rows += g.rows_bytes; d_state += g.state_bytes; d_trace += g.trace_bytes; d_ops += g.ops_bytes;
-        band0 += g.W; max_n = std::max(max_n, jobs[j].n);
+        J.state = nullptr; J.band0 = 0;
+        if (couple_of[j] < 0) {
+            J.state = reinterpret_cast<int*>(d_state); d_state += g.state_bytes;
+            J.band0 = sband0; sband0 += g.W;
+            singles.push_back(J);
+        } else {
+            TraceCouple& C = tc[couple_of[j]];
+            if (C.ja == j) {                                    // the couple's geometry and state: set once
+                C.W = g.W; C.S_total = g.S_total; C.band0 = cband0; cband0 += g.W;
+                C.state = reinterpret_cast<int*>(d_state); d_state += (size_t)g.W * NSP * 64 * sizeof(int);
+            }
+        }
+        d_seq += g.seq_bytes; d_rows += g.rows_bytes; d_trace += g.trace_bytes; d_ops += g.ops_bytes;
+        max_n = std::max(max_n, jobs[j].n);
     }
-    if ((rc = e->check(hipMemcpyAsync(d_jobs, tj.data(), tj.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D jobs")))
+    // couples were numbered in creation order but their bands in job order of their first member: renumber by band0
+    std::sort(tc.begin(), tc.end(), [](const TraceCouple& x, const TraceCouple& y) { return x.band0 < y.band0; });
+    if ((rc = e->check(hipMemcpyAsync(d_jobs, tj.data(), tj.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D jobs")) ||
+        (n_singles && (rc = e->check(hipMemcpyAsync(d_singles, singles.data(), singles.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D singles"))) ||
+        (n_couples && (rc = e->check(hipMemcpyAsync(d_couples, tc.data(), tc.size() * sizeof(TraceCouple), hipMemcpyHostToDevice, s), "H2D couples"))))
         return rc;
 
     PsaTraceArgs A;
-    A.jobs = d_jobs; A.n_jobs = n_jobs; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
+    A.jobs = d_singles; A.n_jobs = n_singles; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
+    PsaTracePackedArgs B;
+    B.jobs = d_jobs; B.couples = d_couples; B.n_couples = n_couples; B.T = T; B.M = p->M; B.X = p->X; B.E = p->E; B.O = p->O;
+    {
+        const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
+        B.pe = ae | (ae << 16); B.po = ao | (ao << 16); B.pm = am | (am << 16); B.pmx = amx | (amx << 16);
+    }
 
     e->timing_begin(s);
     hipLaunchKernelGGL(psa_trace_init_kernel, dim3((unsigned)std::min(64, (max_n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, s,
@@ -457,27 +498,36 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     int launches = 1;
     // band w of a job may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
     int64_t D = 0;
-    for (int j = 0; j < n_jobs; ++j)
-        D = std::max<int64_t>(D, ((int64_t)tj[j].S_total + (int64_t)(tj[j].W - 1) * (T + 64) + T - 1) / T);
+    for (const TraceJob& J : singles) D = std::max<int64_t>(D, ((int64_t)J.S_total + (int64_t)(J.W - 1) * (T + 64) + T - 1) / T);
+    for (const TraceCouple& C : tc) D = std::max<int64_t>(D, ((int64_t)C.S_total + (int64_t)(C.W - 1) * (T + 64) + T - 1) / T);
+    // range of bands with work in launch d: S_w(d) > 0 and S_w(d-1) < S_total
+    auto active = [&](int64_t d, int W, int S_total, int band0, int64_t& g_lo, int64_t& g_hi) {
+        int64_t w_hi = ((d + 1) * T + (T + 64) - 1) / (T + 64);               // first w with S_w(d) <= 0
+        const int64_t w_lo = (d * T - S_total < 0) ? 0 : (d * T - S_total) / (T + 64);   // conservative
+        w_hi = std::min<int64_t>(W, w_hi);
+        if (w_lo >= w_hi) return;
+        g_lo = std::min(g_lo, band0 + w_lo); g_hi = std::max(g_hi, band0 + w_hi);
+    };
     for (int64_t d = 0; d < D; ++d) {
-        // group-wide range of bands with work in this launch: per job, S_w(d) > 0 and S_w(d-1) < S_total
-        int64_t g_lo = total_bands, g_hi = 0;
-        for (int j = 0; j < n_jobs; ++j) {
-            int64_t w_hi = ((d + 1) * T + (T + 64) - 1) / (T + 64);           // first w with S_w(d) <= 0
-            int64_t w_lo = (d * T - tj[j].S_total < 0) ? 0 : (d * T - tj[j].S_total) / (T + 64);   // conservative
-            w_hi = std::min<int64_t>(tj[j].W, w_hi);
-            if (w_lo >= w_hi) continue;
-            g_lo = std::min(g_lo, tj[j].band0 + w_lo); g_hi = std::max(g_hi, tj[j].band0 + w_hi);
+        int64_t g_lo = single_bands, g_hi = 0;
+        for (const TraceJob& J : singles) active(d, J.W, J.S_total, J.band0, g_lo, g_hi);
+        if (g_lo < g_hi) {
+            A.d = (int)d; A.g_lo = (int)g_lo; A.g_hi = (int)g_hi;
+            hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, s, A);
+            ++launches;
         }
-        if (g_lo >= g_hi) continue;
-        A.d = (int)d; A.g_lo = (int)g_lo; A.g_hi = (int)g_hi;
-        const int blocks = (int)((g_hi - g_lo + 3) / 4);
-        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3(blocks), dim3(256), 0, s, A);
-        ++launches;
+        g_lo = couple_bands; g_hi = 0;
+        for (const TraceCouple& C : tc) active(d, C.W, C.S_total, C.band0, g_lo, g_hi);
+        if (g_lo < g_hi) {
+            B.d = (int)d; B.g_lo = (int)g_lo; B.g_hi = (int)g_hi;
+            launch_psa_trace_packed_tile(B, (int)((g_hi - g_lo + 3) / 4), s);
+            ++launches;
+        }
     }
-    hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_jobs), dim3(256), 0, s, d_jobs);
+    if (n_singles) hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_singles), dim3(256), 0, s, d_singles);
+    if (n_couples) launch_psa_trace_packed_finish(d_jobs, d_couples, n_couples, s);
     if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(n_jobs), dim3(64), 0, s, d_jobs);
-    launches += 2;
+    launches += 3;
     e->n_launches = launches;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "psa_align launches"))) return rc;
@@ -611,7 +661,8 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
     const size_t held = e->in_seqs.bytes + e->rows.bytes + e->scratch.bytes + e->trace.bytes + e->scratch2.bytes + e->in_meta.bytes;
     size_t budget = (size_t)((double)(free_b + held) * 0.85);
     if (const char* v = getenv("TSTA_ALIGN_BUDGET_MB")) budget = std::min(budget, (size_t)atoll(v) << 20);
-    auto job_bytes = [&](const HostJob& J) { return Rsel == 4 ? JobGeom<4>(J.n, J.m, true).total() : JobGeom<2>(J.n, J.m, true).total(); };
+    // (a coupled job is laid out for its couple's geometry: up to 1.25x its own cells)
+    auto job_bytes = [&](const HostJob& J) { return Rsel == 4 ? JobGeom<4>(J.n, J.m, true).total() * 5 / 4 : JobGeom<2>(J.n, J.m, true).total(); };
     std::vector<HostJob> group;
     std::vector<int64_t> group_idx;
     size_t used = 0;

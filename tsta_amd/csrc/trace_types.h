@@ -1,0 +1,57 @@
+// trace_types.h — device-side descriptors shared by the trace-fill kernels (psa_trace.hip: int32, one pair per wave;
+// psa_trace_packed.hip: packed 16-bit, two pairs per wave) and the walker.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsta {
+
+// one oriented pair (a = columns = longer sequence, b = rows) of a group, device-resident
+struct TraceJob {
+    const uint8_t* a; const uint8_t* b;
+    int n, m;
+    int2*     rows;                 // [W+1][row_stride]: rows[w] = top row of band w ({H, Ebar} per column)
+    int64_t   row_stride;
+    int*      state;                // [W][NS][64] per-lane DP state between tiles
+    uint8_t*  trace;                // [W][band_bytes]
+    int64_t   band_bytes;
+    int       W, S_total;           // bands, total steps per band (multiple of 64)
+    int       band0;                // index of this job's first band among the bands of the group
+    uint8_t*  ops;                  // walker output (see WalkArgs)
+    int*      out;                  // [8]: maxsorce, H(m,n), #ops, final i, final j
+};
+
+struct PsaTraceArgs {
+    const TraceJob* jobs; int n_jobs;
+    int g_lo, g_hi;                 // range of group-wide band indices this launch covers
+    int T, d;                       // tile length (steps), launch index
+    int M, X, E, O;
+};
+
+template <int R> struct TraceCfg {
+    static constexpr int SPB = 16 / R;          // steps per 16-byte trace group
+    static constexpr int NS = 2 * R + 5;        // state ints per lane
+};
+
+// two jobs of similar geometry sharing the waves of the packed trace fill: the couple sweeps max(n) columns and
+// max(m) rows; both jobs' rows / trace buffers are laid out for THAT geometry (cells outside a job are garbage nobody reads)
+struct TraceCouple {
+    int  ja, jb;                    // indices into the job table
+    int  band0;                     // first band among the bands of all couples of the group
+    int  W, S_total;                // bands / steps per band of the couple
+    int* state;                     // [W][2R+8][64] packed per-lane state between tiles
+};
+
+struct PsaTracePackedArgs {
+    const TraceJob* jobs; const TraceCouple* couples; int n_couples;
+    int g_lo, g_hi;
+    int T, d;
+    int M, X, E, O;
+    unsigned pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
+};
+
+constexpr int kPackedTraceR = 4;    // rows per lane of the packed trace fill (trace layout = TraceCfg<4>)
+void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream);
+void launch_psa_trace_packed_finish(const TraceJob* jobs, const TraceCouple* couples, int n_couples, hipStream_t stream);
+
+}  // namespace tsta
