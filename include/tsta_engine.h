@@ -53,6 +53,7 @@ void tsta_free(void* p);                                   /* frees host buffers
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_packed"     1 (default) | 0: tsta_psa_align_batch never couples two pairs per wave (packed 16-bit trace fill)
+ *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel

@@ -166,7 +166,7 @@ def test_batch_ragged_vs_oracle(eng, scoring):
 
 
 def test_batch_many_bands_uses_tall_bands_and_long_tiles(eng):
-    # enough bands in flight (>= 16 per CU at 256 rows each) switch the group to R=4 / T=256; results do not change,
+    # enough bands in flight (>= 16 per CU at 256 rows each) switch the group to R=4 / T=128; results do not change,
     # also with the other instantiation forced and with groups split by a small workspace budget
     cases = _ragged_cases(43, 24, 3000, 9000) + _ragged_cases(44, 200, 1500, 2500)
     want = [util.oracle_align(s1, s2) for s1, s2 in cases[:24]]
@@ -176,9 +176,14 @@ def test_batch_many_bands_uses_tall_bands_and_long_tiles(eng):
     try:
         eng.set_option("trace_rows", 2); eng.set_option("trace_tile", 128)
         res2 = eng.psa_align_batch(cases)
+        # R=4: ~100 couples in the packed fill, split over 4 overlapping launch sequences / kept on one stream
+        eng.set_option("trace_rows", 4); eng.set_option("trace_tile", 0)
+        res4 = eng.psa_align_batch(cases)
+        eng.set_option("trace_streams", 1)
+        res4s = eng.psa_align_batch(cases)
     finally:
-        eng.set_option("trace_rows", 0); eng.set_option("trace_tile", 0)
-    assert res2 == res
+        eng.set_option("trace_rows", 0); eng.set_option("trace_tile", 0); eng.set_option("trace_streams", 0)
+    assert res2 == res and res4 == res and res4s == res
 
 
 def test_batch_split_into_groups_by_budget(eng, monkeypatch):

@@ -17,12 +17,14 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     hipStream_t timing_stream = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams: independent launch sequences of one call overlap
+    hipEvent_t  ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool        timing_valid = false;
     int         n_launches = 0;
     char        err[512] = {0};
 
     // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
-    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1;
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0;
 
     DevBuf counter;      // ticket counters / flags (zeroed per launch)
     DevBuf rows;         // PSA per-wave boundary rows

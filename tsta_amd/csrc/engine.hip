@@ -89,6 +89,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     e->device = device;
     if (const char* v = getenv("TSTA_PSA_PACKED")) e->opt_psa_packed = atoi(v);
     if (const char* v = getenv("TSTA_PSA_ELIDE")) e->opt_psa_elide = atoi(v) != 0;
+    if (const char* v = getenv("TSTA_TRACE_STREAMS")) e->opt_trace_streams = atoi(v);
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
@@ -147,6 +148,8 @@ void tsta_engine_destroy(tsta_engine* eng)
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (int g = 0; g < 3; ++g) { if (e->side[g]) (void)hipStreamDestroy(e->side[g]); if (e->ev_join[g]) (void)hipEventDestroy(e->ev_join[g]); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -162,6 +165,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
     if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
     if (!strcmp(key, "psa_elide") && (v == 0 || v == 1)) { e->opt_psa_elide = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_streams") && (v == 0 || v == 1)) { e->opt_trace_streams = v; return TSTA_OK; }
     if (!strcmp(key, "trace_packed") && (v == 0 || v == 1)) { e->opt_trace_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }

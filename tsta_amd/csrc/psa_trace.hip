@@ -491,11 +491,40 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         B.pe = ae | (ae << 16); B.po = ao | (ao << 16); B.pm = am | (am << 16); B.pmx = amx | (amx << 16);
     }
+    // The couples are independent of each other: split them into up to 4 chunks with their own band numbering and
+    // their own stream, so that the launch sequences overlap (one sequence's launch gaps and half-empty tails are
+    // filled by the others' waves).  Chunk 0 rides on the engine's stream.
+    int n_chunks = (n_couples >= 8 && e->opt_trace_streams != 1) ? 4 : 1;
+    for (int g = 0; g + 1 < n_chunks; ++g) {
+        if (!e->side[g] && hipStreamCreateWithFlags(&e->side[g], hipStreamNonBlocking) != hipSuccess) { n_chunks = 1; break; }
+        if (!e->ev_join[g] && hipEventCreateWithFlags(&e->ev_join[g], hipEventDisableTiming) != hipSuccess) { n_chunks = 1; break; }
+    }
+    if (n_chunks > 1 && !e->ev_fork && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) n_chunks = 1;
+    int chunk_lo[5] = {0, n_couples, n_couples, n_couples, n_couples};
+    if (n_chunks > 1) {
+        int g = 1;
+        for (int c = 0; c < n_couples && g < n_chunks; ++c)
+            if ((int64_t)tc[c].band0 * n_chunks >= (int64_t)g * couple_bands) chunk_lo[g++] = c;
+        for (; g < n_chunks; ++g) chunk_lo[g] = n_couples;
+        chunk_lo[n_chunks] = n_couples;
+        for (int q = 0; q < n_chunks; ++q) {                   // band numbers relative to the chunk
+            if (chunk_lo[q] >= chunk_lo[q + 1]) continue;
+            const int b0 = tc[chunk_lo[q]].band0;
+            for (int c = chunk_lo[q]; c < chunk_lo[q + 1]; ++c) tc[c].band0 -= b0;
+        }
+        if ((rc = e->check(hipMemcpyAsync(d_couples, tc.data(), tc.size() * sizeof(TraceCouple), hipMemcpyHostToDevice, s), "H2D couples")))
+            return rc;
+    }
 
     e->timing_begin(s);
     hipLaunchKernelGGL(psa_trace_init_kernel, dim3((unsigned)std::min(64, (max_n + 255) / 256), (unsigned)n_jobs), dim3(256), 0, s,
                        d_jobs, p->E, p->O);
     int launches = 1;
+    if (n_chunks > 1) {                                         // fork: the side streams start after the uploads + init
+        if ((rc = e->check(hipEventRecord(e->ev_fork, s), "hipEventRecord(fork)"))) return rc;
+        for (int q = 1; q < n_chunks; ++q)
+            if ((rc = e->check(hipStreamWaitEvent(e->side[q - 1], e->ev_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+    }
     // band w of a job may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
     int64_t D = 0;
     for (const TraceJob& J : singles) D = std::max<int64_t>(D, ((int64_t)J.S_total + (int64_t)(J.W - 1) * (T + 64) + T - 1) / T);
@@ -516,16 +545,23 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, s, A);
             ++launches;
         }
-        g_lo = couple_bands; g_hi = 0;
-        for (const TraceCouple& C : tc) active(d, C.W, C.S_total, C.band0, g_lo, g_hi);
-        if (g_lo < g_hi) {
+        for (int q = 0; q < n_chunks; ++q) {
+            g_lo = couple_bands; g_hi = 0;
+            for (int c = chunk_lo[q]; c < chunk_lo[q + 1]; ++c) active(d, tc[c].W, tc[c].S_total, tc[c].band0, g_lo, g_hi);
+            if (g_lo >= g_hi) continue;
+            B.couples = d_couples + chunk_lo[q]; B.n_couples = chunk_lo[q + 1] - chunk_lo[q];
             B.d = (int)d; B.g_lo = (int)g_lo; B.g_hi = (int)g_hi;
-            launch_psa_trace_packed_tile(B, (int)((g_hi - g_lo + 3) / 4), s);
+            launch_psa_trace_packed_tile(B, (int)((g_hi - g_lo + 3) / 4), q == 0 ? s : e->side[q - 1]);
             ++launches;
         }
     }
+    for (int q = 1; q < n_chunks; ++q) {                         // join
+        if ((rc = e->check(hipEventRecord(e->ev_join[q - 1], e->side[q - 1]), "hipEventRecord(join)")) ||
+            (rc = e->check(hipStreamWaitEvent(s, e->ev_join[q - 1], 0), "hipStreamWaitEvent(join)")))
+            return rc;
+    }
     if (n_singles) hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_singles), dim3(256), 0, s, d_singles);
-    if (n_couples) launch_psa_trace_packed_finish(d_jobs, d_couples, n_couples, s);
+    if (n_couples) launch_psa_trace_packed_finish(d_jobs, d_couples, n_couples, s);     // (does not use band0)
     if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(n_jobs), dim3(64), 0, s, d_jobs);
     launches += 3;
     e->n_launches = launches;
@@ -654,7 +690,7 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
     // longer tiles cost fewer instructions per cell; a few long pairs want many short bands instead (see tsta_psa_align)
     const int R_env = e->opt_trace_rows;
     const int Rsel = (R_env == 2 || R_env == 4) ? R_env : (bands4 >= (int64_t)e->n_cu * 16 ? 4 : 2);
-    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : (bands4 >= (int64_t)e->n_cu * 16 ? 256 : 64);
+    const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : (bands4 >= (int64_t)e->n_cu * 16 ? 128 : 64);
     // groups of pairs whose workspaces (1 B per DP cell of trace, mostly) fit the device together
     size_t free_b = 0, total_b = 0;
     if ((rc = e->check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo")) != TSTA_OK) return rc;

@@ -212,13 +212,13 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
     s.sh = pack2(kBias, kBias); s.se = s.sh; s.mx = 0u;
     acc.ancA = 0; acc.ancB = 0;
 
+    // top-row entries and column characters of a block are loaded one block ahead (within the tile: everything this
+    // launch may read of the band above was written by earlier launches)
+    int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
+    int naA = 0, naB = 0;
+    { const int c = s0 + opaque(lane); if (c < nA) { ntA = topA[c]; naA = aA[c]; } if (c < nB) { ntB = topB[c]; naB = aB[c]; } }
     for (int t0 = s0; t0 < s1; t0 += 64) {
         const int ln = opaque(lane);
-        const int c = t0 + ln;
-        int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
-        int naA = 0, naB = 0;
-        if (c < nA) { ntA = topA[c]; naA = aA[c]; }
-        if (c < nB) { ntB = topB[c]; naB = aB[c]; }
         if (t0 > 0 && t0 < n) {
             // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
             fold_mx(s.mx, acc);
@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
             s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
         }
         s.ach = pack2(naA << 8, naB << 8);
+        if (t0 + 64 < s1) {
+            const int cn = t0 + 64 + ln;
+            ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
+            if (cn < nA) { ntA = topA[cn]; naA = aA[cn]; }
+            if (cn < nB) { ntB = topB[cn]; naB = aB[cn]; }
+        }
         uint4* tqA = reinterpret_cast<uint4*>(tbandA) + ((size_t)(t0 / SPB) * 64 + ln);
         uint4* tqB = reinterpret_cast<uint4*>(tbandB) + ((size_t)(t0 / SPB) * 64 + ln);
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
