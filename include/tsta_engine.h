@@ -48,6 +48,8 @@ void tsta_free(void* p);                                   /* frees host buffers
 
 /* Tuning knobs (tests / experiments; results never depend on them).  Keys:
  *   "psa_packed"      -1 auto (default) | 0 never use the packed 16-bit kernel | 8 / 16 / 32 force it with that many rows per lane
+ *   "psa_bands"        -1 auto (default) | 0 never | 8 / 16: run the bands of every couple concurrently (band pipeline, K1b)
+ *                      with that many rows per lane; auto uses it for batches too small to fill the chip with K1p
  *   "psa_elide"        1 (default) | 0: packed kernel keeps the running max in every block, also where a bound shows
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs

@@ -361,3 +361,45 @@ def test_fuzz_packed_vs_int32_vs_oracle(eng):
                 assert np.array_equal(res[0], util.oracle_maxscore_batch(pairs, M=M, X=X, E=E, O=O)), (trial, M, X, E, O)
     finally:
         eng.set_option("psa_packed", -1)
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=4, X=-6, E=-3, O=-5),
+                                     dict(M=10, X=-10, E=-3, O=-12)])
+def test_band_pipeline_for_small_batches(eng, scoring):
+    # K1b (psa_score_bands_kernel): a batch too small to fill the chip runs the bands of every couple concurrently.
+    # Equal and unequal couples, an odd pair out, pairs shorter than one band, sizes around band (512 / 1024 rows) and
+    # block (64 columns) edges, related / unrelated / identical content; forced R=8 / R=16 / off, two tile lengths.
+    rng = np.random.default_rng(123)
+    pairs = []
+    for (n, m) in [(1024, 1024), (1025, 1023), (2048, 2047), (513, 511), (5000, 5000), (5000, 4990), (7000, 3000),
+                   (6900, 3100), (3000, 64), (3000, 60), (9000, 8900), (8800, 9000), (100, 90), (1500, 1500), (4097, 4095)]:
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = len(pairs) % 3
+        if kind == 0:
+            b = _fixed_len(util.mutate(a, int(rng.integers(1 << 30)), 0.07), m, 3)
+        elif kind == 1:
+            b = util.random_dna(int(rng.integers(1 << 30)), m)
+        else:
+            b = _fixed_len(a.copy(), m, 4)
+        pairs.append((a, b) if len(pairs) % 2 else (b, a))
+    want = util.oracle_maxscore_batch(pairs, **scoring)
+    try:
+        for mode in (-1, 8, 16, 0):
+            eng.set_option("psa_bands", mode)
+            for tile in (0, 128):
+                eng.set_option("trace_tile", tile)
+                got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+                assert np.array_equal(got, want), (mode, tile, scoring, got.tolist(), want.tolist())
+    finally:
+        eng.set_option("psa_bands", -1); eng.set_option("trace_tile", 0)
+
+
+def test_band_pipeline_few_long_pairs(eng):
+    # a handful of 30 kbp pairs: previously one wave each (or one pair at a time); now every band of every pair in flight
+    pairs = []
+    for i in range(7):
+        a = util.random_dna(4000 + i, 30_000 - 17 * i)
+        pairs.append((a, util.mutate(a, 4100 + i, 0.04)[:29_000] if i % 2 else util.random_dna(4200 + i, 29_500)))
+    got = eng.psa_score_batch(pairs)
+    want = util.oracle_maxscore_batch(pairs)
+    assert np.array_equal(got, want)

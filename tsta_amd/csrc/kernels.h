@@ -56,6 +56,19 @@ struct PsaPackedArgs {
     int32_t  elide;                 // 1: blocks that provably cannot raise the maximum run without the running max
 };
 
+// K1b (psa_trace_packed.hip: psa_score_bands_kernel): band pipeline over the couples of a small batch
+struct PsaBandsArgs {
+    PsaBatchArgs b;                 // batch; b.rows = [pair in couple order][W_max+1][b.row_stride]; b.packed_couples = couples
+    int*     state;                 // [couple][W_max][packed_state_ints(R)][64]
+    const uint8_t* acgt;            // per pair: 1 iff pure ACGT (may be null), as in PsaPackedArgs
+    int32_t  elide;                 // as in PsaPackedArgs
+    int64_t  rows_per_pair;         // (W_max+1) * row_stride
+    int      W_max, T, d;           // bands per pair at max_len, tile length (steps), launch index
+    uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
+};
+void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream);
+void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t stream);
+
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream);
 int  psa_score_blocks_per_cu(int R);
 void launch_dpp_selftest(int* d_out, hipStream_t stream);

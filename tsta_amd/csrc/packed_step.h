@@ -1,0 +1,175 @@
+// packed_step.h — the DP step of the packed 16-bit kernels (K1p psa_score_packed.hip, K1b psa_score_bands_kernel):
+// lane state, the generic step with running max, the elided step in the row-shifted frame, the frame change and the
+// bound that licenses it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "packed_ops.h"
+#include "wave_ops.h"
+
+namespace tsta {
+
+// 0 / M-X per half for (column character, row character):
+//   generic bytes:  min_u16((a ^ b) << 8, M-X)                                              (2 VALU)
+//   PERM couples (both pairs pure ACGT): one v_perm_b32 byte lookup.  The column carries, per pair, a 4-byte table
+//   indexed by the ROW's 2-bit code ((c >> 1) & 3: A 0, C 1, T 2, G 3) holding 0 at the column's own code and M-X
+//   elsewhere; the row register is the byte selector {codeA, 0x0c (-> 0x00), 4 + codeB, 0x0c}: selectors 0-3 read
+//   the second table operand (pair A), 4-7 the first (pair B).
+template <bool PERM>
+__device__ __forceinline__ unsigned mismatch_term(unsigned cch, unsigned cch2, unsigned bch, unsigned pmx)
+{
+    if (PERM) return __builtin_amdgcn_perm(cch2, cch, bch);
+    return pkmin(cch ^ bch, pmx);
+}
+__device__ __forceinline__ unsigned acgt_code(int c) { return ((unsigned)c >> 1) & 3u; }
+// the column's table for one pair: M-X in the four bytes, 0 at the column's own code
+__device__ __forceinline__ unsigned acgt_table(int c, unsigned k4) { return k4 & ~(0xffu << (8 * acgt_code(c))); }
+
+
+template <int R>
+struct PLane {
+    unsigned hl[R];    // H'(row k, previous column)           (biased, packed A|B; H' = H - column*M, see pstep)
+    unsigned fb[R];    // Fbar'(row k, previous column)
+    unsigned bch[R];   // row characters << 8 in each half
+    unsigned hd;       // H'(row above first row, previous column)
+    unsigned hbot, ebot, cch, th, te, ach, sh, se, mx;
+    unsigned cch2, ach2;   // PERM couples: the column character travels as two byte tables (pair A in cch/ach, pair B here)
+    unsigned joff;     // (column of this step - (t0 - 63)) * M in both halves: turns H' back into H for the running max
+};
+
+// All scores are kept in the column-shifted frame  H'(i,j) = H(i,j) - j*M  (same for E, F, Ebar, Fbar).  The
+// diagonal term then needs no "+M":  D' = H'(i-1,j-1) - (match ? 0 : M-X);  the vertical gap is unchanged
+// (E' = Ebar'(i-1,j) - |E|, same column) and the horizontal gap pays the shift:  F' = Fbar'(i,j-1) - (|E|+M).
+// That removes one add per cell; the price is one add + one max per STEP to feed the running max in the H frame.
+template <int R, bool PRED, bool PARTIAL, bool PERM>
+__device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
+                                      const int nvA, const int nvB,
+                                      const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
+                                      const unsigned pf)
+{
+    unsigned hu, eu;
+    if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
+    else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+
+    const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
+    unsigned d = s.hd;
+    unsigned h = 0;
+    unsigned m = 0;                                     // max of this step's H' over the lane's rows
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned e = eu - pe;                      // E' = Ebar'(up) - |E|        (v_sub_u32 on both halves)
+        const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)
+        const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);   // 0 or M-X
+        const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
+        h = pkmax(pkmax(dg, e), f);
+        const unsigned g = h - po;                       // H' + O
+        const unsigned eb = pkmax(e, g);
+        const unsigned fbn = pkmax(f, g);
+        d = s.hl[k];
+        unsigned hv = h;
+        if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);   // rows beyond m of either pair
+        if (PRED) {
+            s.hl[k] = act ? h : s.hl[k];
+            s.fb[k] = act ? fbn : s.fb[k];
+        } else {
+            s.hl[k] = h;
+            s.fb[k] = fbn;
+        }
+        m = (k == 0) ? hv : pkmax(m, hv);
+        eu = eb;
+    }
+    s.hbot = h;
+    s.ebot = eu;
+    if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
+    // running max in the H frame: H - anchor = H' + (column - anchor column)*M ; joff >= 0, no carry across halves
+    unsigned cand = m + s.joff;
+    if (PRED) {                                         // columns outside either pair's sequence do not count
+        const unsigned c = (unsigned)(t - lane);
+        cand &= ((c < (unsigned)nA) ? 0xffffu : 0u) | ((c < (unsigned)nB) ? 0xffff0000u : 0u);
+    }
+    if (PARTIAL) cand &= ((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u);
+    s.mx = pkmax(s.mx, cand);
+    s.joff += pm;
+}
+
+// ---- steady-state step without the running max ("elided" blocks) -------------------------------------------------
+// In the H' frame every transition is <= 0 (diagonal 0 / X-M, vertical -|E|, horizontal -|E|-M, opening O <= 0), so no
+// cell of a 64-step block exceeds the largest H' that ENTERS the block (the lanes' previous-column H', the diagonal
+// entries and the 64 top-row entries), and  H = H' + (column+1)*M  <=  that maximum + (t0+64)*M.  When this bound is
+// <= the maximum the pair has ALREADY reached, the block cannot change maxsorce: every cell is still computed (the
+// bands below need the boundary row), but nothing has to be compared against the running max, and with no maximum to
+// keep the rows need not share a frame either.  Such a block runs in the frame
+//     H*(i,c) = H'(i,c) + |E|*(i - top row of the band) - |E|*(c - (t0-1))  (- a per-band constant, for the u16 range)
+// in which the VERTICAL gap costs nothing (E* = Ebar*(up)), the diagonal still costs 0 / X-M and the horizontal gap
+// 2|E|+M:  8 + 1 VALU per cell pair instead of 11.  State is converted on entry and exit (2R+5 packed adds each, per
+// 64 steps), so blocks of either kind can follow each other freely and results are identical by construction.
+template <int R, bool PERM>
+__device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, const unsigned pmx, const unsigned pf2)
+{
+    unsigned hu, eu;
+    if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
+    else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+    unsigned d = s.hd;
+    unsigned h = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned f = s.fb[k] - pf2;                // F* = Fbar*(left) - (2|E|+M)
+        const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);
+        const unsigned dg = d - tt;
+        h = pkmax(pkmax(dg, eu), f);                     // E* = Ebar*(up): no subtraction
+        const unsigned g = h - po;
+        d = s.hl[k];
+        s.hl[k] = h;
+        s.fb[k] = pkmax(f, g);
+        eu = pkmax(eu, g);
+    }
+    s.hbot = h;
+    s.ebot = eu;
+    s.hd = hu;
+}
+
+// frame change H' -> H* (sign = +1) or back (sign = -1) of everything a lane carries across a block boundary;
+// `after` = 0 at the block's first step, 64 after its last one (the lane has moved 64 columns to the right).
+template <int R>
+__device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const int ae, const int sign, const int after)
+{
+    const int lane_part = (ln - 32) * (R + 1) - after;             // rows above this lane + its column lead, centred
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int v = sign * ae * (lane_part + k + 1);
+        const unsigned pv = pack2(v, v);
+        s.hl[k] = pkadd(s.hl[k], pv);
+        s.fb[k] = pkadd(s.fb[k], pv);
+    }
+    { const int v = sign * ae * lane_part;       const unsigned pv = pack2(v, v); s.hd = pkadd(s.hd, pv); }
+    { const int v = sign * ae * (lane_part + R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
+}
+
+template <int R>
+__device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx(s.mx, acc); }
+
+
+
+// Can the 64-step block starting at t0 raise either pair's maximum?  (see pstep_elided)  Entering H' values: the lanes'
+// previous-column rows, the diagonal entries and the 64 top-row entries; rows beyond the end of a pair hold garbage
+// that no real cell ever reads and do not count.  `in_star`: the lane state is currently in the H* frame.
+template <int R, bool PARTIAL>
+__device__ __forceinline__ bool block_cannot_raise_max(const PLane<R>& s, const PairAcc& acc, const bool in_star, const int ln,
+                                                       const int ae, const int nvA, const int nvB, const bool rowsA, const bool rowsB,
+                                                       const int t0, const int M)
+{
+    const unsigned lane_s = in_star ? pack2(ae * ((ln - 32) * (R + 1)), ae * ((ln - 32) * (R + 1))) : 0u;
+    unsigned v = pkmax(PARTIAL ? (pksub(s.hd, lane_s) & (((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u))) : pksub(s.hd, lane_s),
+                       PARTIAL ? (s.th & ((rowsA ? 0xffffu : 0u) | (rowsB ? 0xffff0000u : 0u))) : s.th);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        unsigned hv = s.hl[k];
+        if (in_star) hv = pksub(hv, pkadd(lane_s, pack2(ae * (k + 1), ae * (k + 1))));        // back to H'
+        if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);
+        v = pkmax(v, hv);
+    }
+    const int ubA = wave_max((int)(v & 0xffffu)) - kBias + acc.baseA + (t0 + 64) * M;
+    const int ubB = wave_max((int)(v >> 16)) - kBias + acc.baseB + (t0 + 64) * M;
+    return ubA <= max(wave_max(acc.mxA), -100) && ubB <= max(wave_max(acc.mxB), -100);
+}
+
+}  // namespace tsta

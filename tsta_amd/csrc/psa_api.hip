@@ -11,6 +11,7 @@
 #include "../../include/tsta_engine.h"
 #include "engine.h"
 #include "kernels.h"
+#include "trace_types.h"
 
 using tsta::Engine;
 
@@ -47,6 +48,28 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int m
         if (!best || cost < best_cost) { best = R; best_cost = cost; }
     }
     return best;
+}
+
+// K1b (band pipeline over the couples of a batch, psa_trace_packed.hip: psa_score_bands_kernel) pays when K1p could
+// not give every SIMD two waves: fewer couples than 2x the SIMDs, sequences of at least two bands.  Returns rows per
+// lane (16 or 8) or 0; `rows_bytes` = the boundary-row workspace it needs (every band of every pair keeps its own row).
+static int psa_bands_rows_per_lane(const tsta_params& p, int64_t couples, int32_t max_len, int n_cu, int mode, size_t* rows_bytes)
+{
+    if (mode == 0 || couples < 1) return 0;
+    if (p.E > 0 || p.O > 0 || p.M < 0 || p.M < p.X || p.M - p.X > 255) return 0;
+    if (p.E < -4096 || p.O < -4096 || p.M > 4096 || p.X < -4096) return 0;
+    const int64_t n_simd = (int64_t)n_cu * 4;
+    if (mode < 0 && couples >= 2 * n_simd) return 0;
+    const int64_t row_stride = ((int64_t)max_len + 63) / 64 * 64 + 64;
+    auto bytes = [&](int R) { return (size_t)couples * 2 * (size_t)(((int64_t)max_len + 64 * R - 1) / (64 * R) + 1) * (size_t)row_stride * sizeof(int2); };
+    auto ok = [&](int R) { return psa_packed_window(p.M, p.X, p.E, p.O, R) < 28000 && bytes(R) <= ((size_t)48 << 30); };
+    int R = 0;
+    if (mode == 16 || mode == 8) R = ok(mode) ? mode : 0;
+    else if (max_len >= 2 * 1024 && ok(16) && couples * (((int64_t)max_len + 1023) / 1024) >= 2 * n_simd) R = 16;   // still >= 2 waves per SIMD
+    else if (max_len >= 2 * 512 && ok(8)) R = 8;
+    else if (max_len >= 2 * 1024 && ok(16)) R = 16;
+    if (R && rows_bytes) *rows_bytes = bytes(R);
+    return R;
 }
 
 // flags[k] = 1 iff both sequences of pair k consist of the bytes 'A', 'C', 'G', 'T' only: such pairs take the
@@ -136,11 +159,15 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     // ---- packed-int16 kernel (K1p) for couples of equal-geometry pairs, when the scoring fits 16-bit lanes
     // one wave nearly saturates a SIMD, so packing two pairs per wave only pays once there are more
     // pairs than SIMDs; below that the int32 kernel keeps every SIMD busy with one pair each
-    const bool enough = n_pairs > (int64_t)e->n_cu * 4 || e->opt_psa_packed > 0;
+    // ---- K1b first: a batch too small to fill the chip with one wave per couple runs the bands of every couple
+    // concurrently (band pipeline, one launch per tile diagonal)
+    size_t bands_rows = 0;
+    const int Rb = e->opt_psa_packed > 0 ? 0 : tsta::psa_bands_rows_per_lane(*p, n_pairs / 2, max_len, e->n_cu, e->opt_psa_bands, &bands_rows);
+    const bool enough = (n_pairs > (int64_t)e->n_cu * 4 || e->opt_psa_packed > 0) && !Rb;
     const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2, e->opt_psa_packed, max_len) : 0;
-    const int64_t couples = Rp ? n_pairs / 2 : 0;
+    const int64_t couples = (Rp || Rb) ? n_pairs / 2 : 0;
     int64_t pblocks = 0;
-    if (couples) {
+    if (couples && Rp) {
         pblocks = std::min<int64_t>((couples + 3) / 4, (int64_t)e->n_cu * tsta::psa_packed_blocks_per_cu(Rp));
         if (pblocks < 1) pblocks = 1;
     }
@@ -151,7 +178,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     if (blocks < 1) blocks = 1;
     const int64_t row_stride = ((int64_t)max_len + 63) / 64 * 64 + 64;
     const size_t need32 = (size_t)blocks * 4 * (size_t)row_stride * sizeof(int2);
-    const size_t need16 = (size_t)pblocks * 4 * 2 * (size_t)row_stride * sizeof(int2);
+    const size_t need16 = Rb ? bands_rows : (size_t)pblocks * 4 * 2 * (size_t)row_stride * sizeof(int2);
     if ((rc = e->reserve(e->rows, need32 + need16, "hipMalloc(boundary rows)")) != TSTA_OK) return rc;
 
     tsta::PsaBatchArgs a;
@@ -171,7 +198,38 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         acgt = reinterpret_cast<const uint8_t*>(e->pair_flags.p);
     e->timing_begin(s);
     int launches = 0;
-    if (couples) {
+    if (couples && Rb) {
+        tsta::PsaBandsArgs ba;
+        ba.b = a;
+        ba.b.rows = a.rows + need32 / sizeof(int2);
+        ba.b.clock_out = nullptr;
+        ba.W_max = (int)(((int64_t)max_len + 64 * Rb - 1) / (64 * Rb));
+        ba.rows_per_pair = (int64_t)(ba.W_max + 1) * row_stride;
+        const size_t state_bytes = (size_t)couples * ba.W_max * tsta::packed_state_ints(Rb) * 64 * sizeof(int);
+        if ((rc = e->reserve(e->scratch2, state_bytes, "hipMalloc(band state)")) != TSTA_OK) return rc;
+        ba.state = reinterpret_cast<int*>(e->scratch2.p);
+        const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
+        ba.pe = ae | (ae << 16); ba.po = ao | (ao << 16); ba.pm = am | (am << 16); ba.pmx = amx | (amx << 16);
+        ba.acgt = acgt;
+        ba.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rb) + (int64_t)ae * (32 * (Rb + 1) + 192) < 28000;
+        if (acgt) {
+            hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,
+                               d_seqs, d_off1, d_len1, d_off2, d_len2, n_pairs, reinterpret_cast<uint8_t*>(e->pair_flags.p));
+            ++launches;
+        }
+        ba.T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : (max_len >= 16384 ? 128 : 64);
+        const int64_t S_total = ((int64_t)max_len + 64 + 63) / 64 * 64;
+        const int64_t D = (S_total + (int64_t)(ba.W_max - 1) * (ba.T + 64) + ba.T - 1) / ba.T;
+        const int64_t bblocks = (couples * ba.W_max + 3) / 4;
+        if (bblocks > 0x7fffffffLL) return TSTA_ERR_UNSUPPORTED;
+        for (int64_t d = 0; d < D; ++d) {
+            ba.d = (int)d;
+            tsta::launch_psa_score_bands(Rb, ba, (int)bblocks, s);
+            ++launches;
+        }
+        tsta::launch_psa_score_bands_finish(Rb, ba, s);
+        ++launches;
+    } else if (couples) {
         tsta::PsaPackedArgs pa;
         pa.b = a;
         pa.b.rows = a.rows + need32 / sizeof(int2);
@@ -232,7 +290,7 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     const size_t nb = (size_t)n_pairs;
     // A handful of long pairs: the batch kernels give each pair one wave, which leaves the chip idle; run every such
     // pair through the pipelined single-pair fill (the bands of one pair spread over many waves) instead.
-    if (n_pairs <= 64) {
+    if (n_pairs <= 64 && (n_pairs == 1 || !tsta::psa_bands_rows_per_lane(*p, 1, 4096, e->n_cu, e->opt_psa_bands, nullptr))) {
         bool all_big = true;
         for (int64_t k = 0; k < n_pairs; ++k) all_big = all_big && (int64_t)len1[k] * len2[k] >= 200000000LL;
         if (all_big) {

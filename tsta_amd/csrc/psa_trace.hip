@@ -391,7 +391,7 @@ static bool packed_trace_fits(const tsta_params& p)
 template <int R, bool TRACE>
 static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs, int T)
 {
-    constexpr int NSP = 2 * kPackedTraceR + 8;
+    constexpr int NSP = packed_state_ints(kPackedTraceR);
     hipStream_t s = e->stream;
     // ---- couples: adjacent jobs in geometry order whose padded sweep stays below 1.25x their own cells
     std::vector<int> lay_n((size_t)n_jobs), lay_m((size_t)n_jobs), couple_of((size_t)n_jobs, -1);

@@ -12,10 +12,16 @@
 // The two jobs of a couple may differ in size: the wave sweeps max(n) columns and max(m) rows, both jobs' boundary
 // rows and trace are laid out for that geometry, and cells outside a job compute garbage that feeds only other such
 // cells, is masked out of the job's running max and lands in trace bytes the walker never visits.
+//
+// The same tile body without the trace (TRACE = false) is K1b, psa_score_bands_kernel: the score-only fill of a
+// batch too small to give every SIMD two waves of K1p — there the bands of every couple run concurrently in the
+// band pipeline instead of one after the other in one wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels.h"
 #include "packed_ops.h"
+#include "packed_step.h"
 #include "trace_types.h"
 #include "wave_ops.h"
 
@@ -44,17 +50,11 @@ __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned k, unsigned c)
 // packed constants of the trace code, pinned in VGPRs
 struct PkConst { unsigned one, mone, k2, k4, k16, k20, k21; };
 
-template <int R>
-struct PTLane {
-    unsigned hl[R], fb[R], bch[R];
-    unsigned hd, hbot, ebot, cch, th, te, ach, sh, se, mx, joff;
-};
-
 // One step of the lane's R rows for both jobs (see psa_score_packed.hip: pstep for the recurrence and the masks);
 // code[k] = per half, the trace byte of row k: nd + 2nf + 4(fge+1) + 16(ege+1) = (nd + 20) + 2nf + 4fge + 16ege with
 // fge, ege in {-1,0,1}; the +20 rides on nd so that every partial sum stays a non-negative byte.
-template <int R, bool PRED, bool PARTIAL>
-__device__ __forceinline__ void ptstep(PTLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
+template <int R, bool PRED, bool PARTIAL, bool TRACE>
+__device__ __forceinline__ void ptstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
                                        const int nvA, const int nvB, const unsigned pe, const unsigned po, const unsigned pm,
                                        const unsigned pmx, const unsigned pf, const PkConst& K, unsigned (&code)[R])
 {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void ptstep(PTLane<R>& s, const int t, const int lane
         const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
         h = pkmax(pkmax(dg, e), f);
         const unsigned g = h - po;                       // H' + O
-        {
+        if (TRACE) {
             const unsigned nd = pkmin((h + K.k20) - dg, K.k21);   // psa.c:294-299: back; min(x,1) + 20 (x >= 0): bytes stay >= 0
             const unsigned nf = pkmin(h - f, K.one);
             const unsigned fge = pk_sign(g, f, K.mone, K.one);    // psa.c:302-313 (fback), one cell to the left of where it is used
@@ -108,37 +108,234 @@ __device__ __forceinline__ void ptstep(PTLane<R>& s, const int t, const int lane
 }
 
 // 64 steps; the trace bytes of every 16/R steps leave as one uint4 per lane and job
-template <int R, bool PRED, bool PARTIAL>
-__device__ __forceinline__ void ptblock(PTLane<R>& s, const int t0, const int lane, const int n, const int nA, const int nB,
+template <int R, bool PRED, bool PARTIAL, bool TRACE>
+__device__ __forceinline__ void ptblock(PLane<R>& s, const int t0, const int lane, const int n, const int nA, const int nB,
                                         const int nvA, const int nvB, const unsigned pe, const unsigned po, const unsigned pm,
                                         const unsigned pmx, const unsigned pf, const PkConst& K,
                                         uint4* __restrict__ tqA, uint4* __restrict__ tqB)
 {
-    static_assert(R == 4, "byte gather below is written for 4 rows per lane");
-    constexpr int SPB = TraceCfg<R>::SPB;
+    if constexpr (TRACE) {
+        static_assert(R == 4, "byte gather below is written for 4 rows per lane");
+        constexpr int SPB = TraceCfg<R>::SPB;
 #pragma unroll 1
-    for (int g = 0; g < 64 / SPB; ++g) {
-        unsigned accA[4], accB[4];
+        for (int g = 0; g < 64 / SPB; ++g) {
+            unsigned accA[4], accB[4];
 #pragma unroll
-        for (int q = 0; q < SPB; ++q) {
-            unsigned code[R];
-            ptstep<R, PRED, PARTIAL>(s, t0 + g * SPB + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
-            // bytes 0 / 2 of the four codes -> one dword per job (v_perm_b32: selectors 0-3 second operand, 4-7 first)
-            const unsigned p01 = __builtin_amdgcn_perm(code[1], code[0], 0x06020400u);   // A0 A1 B0 B1
-            const unsigned p23 = __builtin_amdgcn_perm(code[3], code[2], 0x06020400u);   // A2 A3 B2 B3
-            accA[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-            accB[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+            for (int q = 0; q < SPB; ++q) {
+                unsigned code[R];
+                ptstep<R, PRED, PARTIAL, true>(s, t0 + g * SPB + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
+                // bytes 0 / 2 of the four codes -> one dword per job (v_perm_b32: selectors 0-3 second operand, 4-7 first)
+                const unsigned p01 = __builtin_amdgcn_perm(code[1], code[0], 0x06020400u);   // A0 A1 B0 B1
+                const unsigned p23 = __builtin_amdgcn_perm(code[3], code[2], 0x06020400u);   // A2 A3 B2 B3
+                accA[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                accB[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+            }
+            tqA[(size_t)g * 64] = make_uint4(accA[0], accA[1], accA[2], accA[3]);
+            tqB[(size_t)g * 64] = make_uint4(accB[0], accB[1], accB[2], accB[3]);
         }
-        tqA[(size_t)g * 64] = make_uint4(accA[0], accA[1], accA[2], accA[3]);
-        tqB[(size_t)g * 64] = make_uint4(accB[0], accB[1], accB[2], accB[3]);
+    } else {
+#pragma unroll 2
+        for (int q = 0; q < 64; ++q) {
+            unsigned code[R];
+            ptstep<R, PRED, PARTIAL, false>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
+        }
     }
+}
+
+// everything one wave needs of its couple and band
+struct CoupleView {
+    const uint8_t *aA, *bA, *aB, *bB;           // columns / rows of job A and B
+    int nA, mA, nB, mB;
+    const int2 *topA, *topB;                    // top row of the band ({H, Ebar} per column); nullptr: band 0, the matrix
+    int2 *botA, *botB;                          //   boundary row is computed (psa.c:221-226); bottom row out
+    bool store_bottom;
+    uint8_t *tbandA, *tbandB;                   // TRACE: this band's trace bytes
+    int* st;                                    // this band's per-lane state between tiles
+    int w;                                      // band index
+};
+
+// steps [s0, s1) of one band of one couple
+template <int R, bool TRACE, bool PERM>
+__device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
+                                            const int M, const int E, const int O,
+                                            const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
+                                            const bool elide_ok)
+{
+    static_assert(!(TRACE && PERM), "the trace step has no byte-permute form yet");
+    constexpr int SPB = TraceCfg<TRACE ? R : 4>::SPB;
+    const int nA = V.nA, mA = V.mA, nB = V.nB, mB = V.mB, w = V.w;
+    const int n = max(nA, nB), nmin = min(nA, nB), mmin = min(mA, mB);
+    const uint8_t* __restrict__ aA = V.aA; const uint8_t* __restrict__ bA = V.bA;
+    const uint8_t* __restrict__ aB = V.aB; const uint8_t* __restrict__ bB = V.bB;
+    const unsigned pe = in_vgpr(pe_s), po = in_vgpr(po_s), pm = in_vgpr(pm_s), pmx = in_vgpr(pmx_s);
+    PkConst K;
+    K.one = in_vgpr(0x00010001u); K.mone = in_vgpr(0xffffffffu); K.k2 = in_vgpr(0x00020002u); K.k4 = in_vgpr(0x00040004u);
+    K.k16 = in_vgpr(0x00100010u); K.k20 = in_vgpr(0x00140014u); K.k21 = in_vgpr(0x00150015u);
+    const unsigned pf = pe + pm;
+    const unsigned pf2 = pf + pe;                  // horizontal gap in the frame of the elided blocks
+    const unsigned k4 = (pmx_s & 0xffu) * 0x01010101u;
+    const int ae = -E;
+    constexpr int BAND = 64 * R;
+    const int band_row0 = w * BAND;
+    const bool partial = band_row0 + BAND > mmin;
+    const int i0 = band_row0 + lane * R;
+    const int nvA = mA - i0, nvB = mB - i0;
+    int* st = V.st + lane;
+
+    PLane<R> s;
+    PairAcc acc;
+    bool in_star = false;                          // lane state in the frame of the elided blocks (kept across blocks and tiles)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (PERM) {                                 // byte selector {codeA, ->0, 4 + codeB, ->0}; rows beyond m select 0
+            const unsigned cA = (i0 + k < mA) ? acgt_code(bA[i0 + k]) : 0x0cu;
+            const unsigned cB = (i0 + k < mB) ? 4u + acgt_code(bB[i0 + k]) : 0x0cu;
+            s.bch[k] = cA | 0x0c00u | (cB << 16) | 0x0c000000u;
+        } else {
+            const int cA = (i0 + k < mA) ? ((int)bA[i0 + k] << 8) : 0x1ff;
+            const int cB = (i0 + k < mB) ? ((int)bB[i0 + k] << 8) : 0x1ff;
+            s.bch[k] = pack2(cA, cB);
+        }
+    }
+    const int2* __restrict__ topA = V.topA;
+    const int2* __restrict__ topB = V.topB;
+    int2* __restrict__ botA = V.botA;
+    int2* __restrict__ botB = V.botB;
+    // top-row entry of column c: from the band above, or the matrix boundary row H(0,c+1) = O + (c+1)E, Ebar = H + O
+    auto top_entry = [&](const int2* __restrict__ top, int c) -> int2 {
+        if (top) return top[c];
+        const int h = O + (c + 1) * E;
+        return make_int2(h, h + O);
+    };
+
+    if (s0 == 0) {
+        // anchor of the H' frame: the band's top row at the first column (H' = H - (column index + 1) * M)
+        acc.baseA = __builtin_amdgcn_readfirstlane(top_entry(topA, 0).x) - M;
+        acc.baseB = __builtin_amdgcn_readfirstlane(top_entry(topB, 0).x) - M;
+        acc.mxA = kNegInfP; acc.mxB = kNegInfP;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int hk = hcol0p(i0 + 1 + k, E, O);    // column 0: H' = H
+            s.hl[k] = pack2(hk - acc.baseA + kBias, hk - acc.baseB + kBias);
+            s.fb[k] = pack2(hk + O - acc.baseA + kBias, hk + O - acc.baseB + kBias);
+        }
+        const int hd = hcol0p(i0, E, O);
+        s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
+        s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.cch2 = 0u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) { s.hl[k] = (unsigned)st[(2 * k) * 64]; s.fb[k] = (unsigned)st[(2 * k + 1) * 64]; }
+        s.hd = (unsigned)st[(2 * R) * 64]; s.hbot = (unsigned)st[(2 * R + 1) * 64]; s.ebot = (unsigned)st[(2 * R + 2) * 64];
+        s.cch = (unsigned)st[(2 * R + 3) * 64];
+        if (PERM) s.cch2 = (unsigned)st[(2 * R + 9) * 64];
+        in_star = __builtin_amdgcn_readfirstlane(st[(2 * R + 8) * 64]) != 0;
+        acc.mxA = st[(2 * R + 4) * 64]; acc.mxB = st[(2 * R + 5) * 64];
+        acc.baseA = __builtin_amdgcn_readfirstlane(st[(2 * R + 6) * 64]); acc.baseB = __builtin_amdgcn_readfirstlane(st[(2 * R + 7) * 64]);
+    }
+    s.sh = pack2(kBias, kBias); s.se = s.sh; s.mx = 0u; s.ach2 = 0u;
+    if (!PERM) s.cch2 = 0u;
+    acc.ancA = 0; acc.ancB = 0;
+
+    // top-row entries and column characters of a block are loaded one block ahead (within the tile: everything this
+    // launch may read of the band above was written by earlier launches)
+    int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
+    int naA = 0, naB = 0;
+    { const int c = s0 + opaque(lane); if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; } if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; } }
+    int lag = 64;                                  // columns moved since the H* frame's reference column was set
+    for (int t0 = s0; t0 < s1; t0 += 64) {
+        const int ln = opaque(lane);
+        lag = 64;
+        if (t0 > 0 && t0 < n) {
+            // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
+            fold_mx(s.mx, acc);
+            const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
+            const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
+            // (in the H* frame the reference column moves along with the block: +64|E| on everything)
+            const int star = in_star ? 64 * ae : 0;
+            const unsigned pd = pack2(nbA - acc.baseA - star, nbB - acc.baseB - star);
+            lag = 0;
+            acc.baseA = nbA; acc.baseB = nbB;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
+            s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
+        } else if (t0 >= n) {
+            fold_mx(s.mx, acc);                    // drain block keeps the previous anchor
+        }
+        acc.ancA = acc.baseA + (t0 - 62) * M;      // running-max anchor of this block: column t0-63 in the H frame
+        acc.ancB = acc.baseB + (t0 - 62) * M;
+        s.joff = pack2((63 - ln) * M, (63 - ln) * M);
+        {
+            const int sh_m = (t0 + ln + 1) * M;    // column shift of this lane's top-row entry
+            s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
+            s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
+        }
+        if (PERM) { s.ach = acgt_table(naA, k4); s.ach2 = acgt_table(naB, k4); }
+        else      s.ach = pack2(naA << 8, naB << 8);
+        if (t0 + 64 < s1) {
+            const int cn = t0 + 64 + ln;
+            ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
+            if (cn < nA) { ntA = top_entry(topA, cn); naA = aA[cn]; }
+            if (cn < nB) { ntB = top_entry(topB, cn); naB = aB[cn]; }
+        }
+        uint4* tqA = nullptr; uint4* tqB = nullptr;
+        if (TRACE) {
+            tqA = reinterpret_cast<uint4*>(V.tbandA) + ((size_t)(t0 / SPB) * 64 + ln);
+            tqB = reinterpret_cast<uint4*>(V.tbandB) + ((size_t)(t0 / SPB) * 64 + ln);
+        }
+        const bool steady = t0 >= 64 && t0 + 63 < nmin;
+        if constexpr (TRACE) {
+            if (steady && !partial)      ptblock<R, false, false, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+            else if (steady)             ptblock<R, false, true, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+            else                         ptblock<R, true, true, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+        } else {
+            // score only: K1p's steps, including the blocks that provably cannot raise the maximum (packed_step.h)
+            bool elide = false;
+            if (steady && elide_ok)
+                elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, ae, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
+                                : block_cannot_raise_max<R, false>(s, acc, in_star, ln, ae, nvA, nvB, true, true, t0, M);
+            if (elide != in_star) {                    // frame change only where the kind of block changes
+                if (elide) elided_frame<R>(s, ln, ae, +1, 0);
+                else       elided_frame<R>(s, ln, ae, -1, lag);
+                in_star = elide;
+            }
+            if (elide) {
+                { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
+                { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
+            } else if (steady && !partial) {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            } else if (steady) {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < 64; ++q) pstep<R, true, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            }
+        }
+        const int cs = t0 - 64 + ln;
+        if (V.store_bottom && cs >= 0 && cs < n) {
+            const int sh_m = (cs + 1) * M;
+            botA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
+            botB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
+        }
+    }
+    fold_mx(s.mx, acc);
+#pragma unroll
+    for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = (int)s.hl[k]; st[(2 * k + 1) * 64] = (int)s.fb[k]; }
+    st[(2 * R) * 64] = (int)s.hd; st[(2 * R + 1) * 64] = (int)s.hbot; st[(2 * R + 2) * 64] = (int)s.ebot;
+    st[(2 * R + 3) * 64] = (int)s.cch;
+    st[(2 * R + 4) * 64] = acc.mxA; st[(2 * R + 5) * 64] = acc.mxB;
+    st[(2 * R + 6) * 64] = acc.baseA; st[(2 * R + 7) * 64] = acc.baseB;
+    st[(2 * R + 8) * 64] = in_star ? 1 : 0;
+    if (PERM) st[(2 * R + 9) * 64] = (int)s.cch2;
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePackedArgs A)
 {
-    constexpr int NS = 2 * R + 8;
-    constexpr int SPB = TraceCfg<R>::SPB;
+    constexpr int NS = packed_state_ints(R);
     const int lane = threadIdx.x & 63;
     const int g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (g >= A.g_hi) return;
@@ -155,125 +352,23 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
 
     const TraceJob& JA = A.jobs[C.ja];
     const TraceJob& JB = A.jobs[C.jb];
-    const int nA = JA.n, mA = JA.m, nB = JB.n, mB = JB.m;
-    const int n = max(nA, nB), nmin = min(nA, nB), mmin = min(mA, mB);
-    const int M = A.M, E = A.E, O = A.O;
-    const uint8_t* __restrict__ aA = JA.a; const uint8_t* __restrict__ bA = JA.b;
-    const uint8_t* __restrict__ aB = JB.a; const uint8_t* __restrict__ bB = JB.b;
-    const unsigned pe = in_vgpr(A.pe), po = in_vgpr(A.po), pm = in_vgpr(A.pm), pmx = in_vgpr(A.pmx);
-    PkConst K;
-    K.one = in_vgpr(0x00010001u); K.mone = in_vgpr(0xffffffffu); K.k2 = in_vgpr(0x00020002u); K.k4 = in_vgpr(0x00040004u);
-    K.k16 = in_vgpr(0x00100010u); K.k20 = in_vgpr(0x00140014u); K.k21 = in_vgpr(0x00150015u);
-    const unsigned pf = pe + pm;
-    constexpr int BAND = 64 * R;
-    const int band_row0 = w * BAND;
-    const bool partial = band_row0 + BAND > mmin;
-    const int i0 = band_row0 + lane * R;
-    const int nvA = mA - i0, nvB = mB - i0;
-    int* st = C.state + (size_t)w * NS * 64 + lane;
-
-    PTLane<R> s;
-    PairAcc acc;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int cA = (i0 + k < mA) ? ((int)bA[i0 + k] << 8) : 0x1ff;
-        const int cB = (i0 + k < mB) ? ((int)bB[i0 + k] << 8) : 0x1ff;
-        s.bch[k] = pack2(cA, cB);
-    }
-    const int2* __restrict__ topA = JA.rows + (size_t)w * JA.row_stride;
-    const int2* __restrict__ topB = JB.rows + (size_t)w * JB.row_stride;
-    int2* __restrict__ botA = JA.rows + (size_t)(w + 1) * JA.row_stride;
-    int2* __restrict__ botB = JB.rows + (size_t)(w + 1) * JB.row_stride;
-    uint8_t* tbandA = JA.trace + (size_t)w * JA.band_bytes;
-    uint8_t* tbandB = JB.trace + (size_t)w * JB.band_bytes;
-
-    if (s0 == 0) {
-        // anchor of the H' frame: the band's top row at the first column (H' = H - (column index + 1) * M)
-        acc.baseA = __builtin_amdgcn_readfirstlane(topA[0].x) - M;
-        acc.baseB = __builtin_amdgcn_readfirstlane(topB[0].x) - M;
-        acc.mxA = kNegInfP; acc.mxB = kNegInfP;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int hk = hcol0p(i0 + 1 + k, E, O);    // column 0: H' = H
-            s.hl[k] = pack2(hk - acc.baseA + kBias, hk - acc.baseB + kBias);
-            s.fb[k] = pack2(hk + O - acc.baseA + kBias, hk + O - acc.baseB + kBias);
-        }
-        const int hd = hcol0p(i0, E, O);
-        s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
-        s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u;
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) { s.hl[k] = (unsigned)st[(2 * k) * 64]; s.fb[k] = (unsigned)st[(2 * k + 1) * 64]; }
-        s.hd = (unsigned)st[(2 * R) * 64]; s.hbot = (unsigned)st[(2 * R + 1) * 64]; s.ebot = (unsigned)st[(2 * R + 2) * 64];
-        s.cch = (unsigned)st[(2 * R + 3) * 64];
-        acc.mxA = st[(2 * R + 4) * 64]; acc.mxB = st[(2 * R + 5) * 64];
-        acc.baseA = __builtin_amdgcn_readfirstlane(st[(2 * R + 6) * 64]); acc.baseB = __builtin_amdgcn_readfirstlane(st[(2 * R + 7) * 64]);
-    }
-    s.sh = pack2(kBias, kBias); s.se = s.sh; s.mx = 0u;
-    acc.ancA = 0; acc.ancB = 0;
-
-    // top-row entries and column characters of a block are loaded one block ahead (within the tile: everything this
-    // launch may read of the band above was written by earlier launches)
-    int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
-    int naA = 0, naB = 0;
-    { const int c = s0 + opaque(lane); if (c < nA) { ntA = topA[c]; naA = aA[c]; } if (c < nB) { ntB = topB[c]; naB = aB[c]; } }
-    for (int t0 = s0; t0 < s1; t0 += 64) {
-        const int ln = opaque(lane);
-        if (t0 > 0 && t0 < n) {
-            // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
-            fold_mx(s.mx, acc);
-            const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
-            const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
-            const unsigned pd = pack2(nbA - acc.baseA, nbB - acc.baseB);
-            acc.baseA = nbA; acc.baseB = nbB;
-#pragma unroll
-            for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
-            s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
-        } else if (t0 >= n) {
-            fold_mx(s.mx, acc);                    // drain block keeps the previous anchor
-        }
-        acc.ancA = acc.baseA + (t0 - 62) * M;      // running-max anchor of this block: column t0-63 in the H frame
-        acc.ancB = acc.baseB + (t0 - 62) * M;
-        s.joff = pack2((63 - ln) * M, (63 - ln) * M);
-        {
-            const int sh_m = (t0 + ln + 1) * M;    // column shift of this lane's top-row entry
-            s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
-            s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
-        }
-        s.ach = pack2(naA << 8, naB << 8);
-        if (t0 + 64 < s1) {
-            const int cn = t0 + 64 + ln;
-            ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
-            if (cn < nA) { ntA = topA[cn]; naA = aA[cn]; }
-            if (cn < nB) { ntB = topB[cn]; naB = aB[cn]; }
-        }
-        uint4* tqA = reinterpret_cast<uint4*>(tbandA) + ((size_t)(t0 / SPB) * 64 + ln);
-        uint4* tqB = reinterpret_cast<uint4*>(tbandB) + ((size_t)(t0 / SPB) * 64 + ln);
-        const bool steady = t0 >= 64 && t0 + 63 < nmin;
-        if (steady && !partial)      ptblock<R, false, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-        else if (steady)             ptblock<R, false, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-        else                         ptblock<R, true, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-        const int cs = t0 - 64 + ln;
-        if (cs >= 0 && cs < n) {
-            const int sh_m = (cs + 1) * M;
-            botA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
-            botB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
-        }
-    }
-    fold_mx(s.mx, acc);
-#pragma unroll
-    for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = (int)s.hl[k]; st[(2 * k + 1) * 64] = (int)s.fb[k]; }
-    st[(2 * R) * 64] = (int)s.hd; st[(2 * R + 1) * 64] = (int)s.hbot; st[(2 * R + 2) * 64] = (int)s.ebot;
-    st[(2 * R + 3) * 64] = (int)s.cch;
-    st[(2 * R + 4) * 64] = acc.mxA; st[(2 * R + 5) * 64] = acc.mxB;
-    st[(2 * R + 6) * 64] = acc.baseA; st[(2 * R + 7) * 64] = acc.baseB;
+    CoupleView V;
+    V.aA = JA.a; V.bA = JA.b; V.aB = JB.a; V.bB = JB.b;
+    V.nA = JA.n; V.mA = JA.m; V.nB = JB.n; V.mB = JB.m;
+    V.topA = JA.rows + (size_t)w * JA.row_stride; V.topB = JB.rows + (size_t)w * JB.row_stride;
+    V.botA = JA.rows + (size_t)(w + 1) * JA.row_stride; V.botB = JB.rows + (size_t)(w + 1) * JB.row_stride;
+    V.store_bottom = true;
+    V.tbandA = JA.trace + (size_t)w * JA.band_bytes; V.tbandB = JB.trace + (size_t)w * JB.band_bytes;
+    V.st = C.state + (size_t)w * NS * 64;
+    V.w = w;
+    packed_tile<R, true, false>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, false);
 }
 
 // per couple (blockIdx.x): out[0] of both jobs = max over all lanes' running maxima, floored at -100 (psa.c:590)
 template <int R>
 __global__ void psa_trace_packed_finish_kernel(const TraceJob* jobs, const TraceCouple* couples)
 {
-    constexpr int NS = 2 * R + 8;
+    constexpr int NS = packed_state_ints(R);
     const TraceCouple& C = couples[blockIdx.x];
     int mxA = kNegInfP, mxB = kNegInfP;
     for (int idx = threadIdx.x; idx < C.W * 64; idx += blockDim.x) {
@@ -292,6 +387,92 @@ __global__ void psa_trace_packed_finish_kernel(const TraceJob* jobs, const Trace
         jobs[C.ja].out[0] = max(redA[0], -100); jobs[C.ja].out[1] = 0;
         jobs[C.jb].out[0] = max(redB[0], -100); jobs[C.jb].out[1] = 0;
     }
+}
+
+// ---- K1b: score-only band pipeline for batches that cannot give every SIMD two waves of K1p ------------------------
+// Couples and orientation exactly as in K1p (adjacent pairs of the geometry order, psa_couple_is_packed; K1 takes the
+// rest); workspaces are laid out uniformly for max_len so that a wave finds its couple and band by division:
+//   band g -> couple g / W_max, band g % W_max;  rows: [pair][W_max+1][row_stride] int2;  state: [couple][W_max][2R+8][64]
+template <int R>
+__global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
+{
+    constexpr int NS = packed_state_ints(R);
+    const PsaBatchArgs& A = P.b;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t c = g / P.W_max;
+    const int w = (int)(g % P.W_max);
+    if (c >= A.packed_couples) return;
+    if (!psa_couple_is_packed(A.len1, A.len2, A.order, c)) return;          // K1 (int32) takes these two pairs
+    const int64_t pa = psa_pair_at(A.order, 2 * c), pb = psa_pair_at(A.order, 2 * c + 1);
+    const int l1a = A.len1[pa], l2a = A.len2[pa], l1b = A.len1[pb], l2b = A.len2[pb];
+    const uint8_t* s1a = A.seqs + A.off1[pa]; const uint8_t* s2a = A.seqs + A.off2[pa];
+    const uint8_t* s1b = A.seqs + A.off1[pb]; const uint8_t* s2b = A.seqs + A.off2[pb];
+    const bool swa = l2a > l1a, swb = l2b > l1b;                             // psa.c:194-199
+    CoupleView V;
+    V.aA = swa ? s2a : s1a; V.bA = swa ? s1a : s2a; V.aB = swb ? s2b : s1b; V.bB = swb ? s1b : s2b;
+    V.nA = swa ? l2a : l1a; V.mA = swa ? l1a : l2a; V.nB = swb ? l2b : l1b; V.mB = swb ? l1b : l2b;
+    const int n = max(V.nA, V.nB), m = max(V.mA, V.mB);
+    const int W = (m + 64 * R - 1) / (64 * R);
+    if (w >= W) return;
+    const int S_total = (n + 64 + 63) / 64 * 64;
+    const int shift = w * (P.T + 64);
+    int s0 = P.d * P.T - shift, s1 = (P.d + 1) * P.T - shift;
+    s0 = max(0, min(s0, S_total));
+    s1 = max(0, min(s1, S_total));
+    if (s0 >= s1) return;
+    int2* rowsA = A.rows + (size_t)(2 * c) * P.rows_per_pair;
+    int2* rowsB = rowsA + P.rows_per_pair;
+    V.topA = w ? rowsA + (size_t)w * A.row_stride : nullptr; V.topB = w ? rowsB + (size_t)w * A.row_stride : nullptr;
+    V.botA = rowsA + (size_t)(w + 1) * A.row_stride; V.botB = rowsB + (size_t)(w + 1) * A.row_stride;
+    V.store_bottom = w + 1 < W;
+    V.tbandA = nullptr; V.tbandB = nullptr;
+    V.st = P.state + ((size_t)c * P.W_max + w) * NS * 64;
+    V.w = w;
+    // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
+    const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
+    if (perm) packed_tile<R, false, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    else      packed_tile<R, false, false>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+}
+
+// per couple (blockIdx.x): out[pair] = max over the bands' lanes, floored at -100 (psa.c:110,590)
+template <int R>
+__global__ void psa_score_bands_finish_kernel(PsaBandsArgs P)
+{
+    constexpr int NS = packed_state_ints(R);
+    const PsaBatchArgs& A = P.b;
+    const int64_t c = blockIdx.x;
+    if (!psa_couple_is_packed(A.len1, A.len2, A.order, c)) return;
+    const int64_t pa = psa_pair_at(A.order, 2 * c), pb = psa_pair_at(A.order, 2 * c + 1);
+    const int mA = min(A.len1[pa], A.len2[pa]), mB = min(A.len1[pb], A.len2[pb]);
+    const int W = (max(mA, mB) + 64 * R - 1) / (64 * R);
+    const int* state = P.state + (size_t)c * P.W_max * NS * 64;
+    int mxA = kNegInfP, mxB = kNegInfP;
+    for (int idx = threadIdx.x; idx < W * 64; idx += blockDim.x) {
+        const int w = idx / 64, lane = idx % 64;
+        mxA = max(mxA, state[(size_t)w * NS * 64 + (2 * R + 4) * 64 + lane]);
+        mxB = max(mxB, state[(size_t)w * NS * 64 + (2 * R + 5) * 64 + lane]);
+    }
+    __shared__ int redA[256], redB[256];
+    redA[threadIdx.x] = mxA; redB[threadIdx.x] = mxB;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { redA[threadIdx.x] = max(redA[threadIdx.x], redA[threadIdx.x + o]); redB[threadIdx.x] = max(redB[threadIdx.x], redB[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { A.out[pa] = max(redA[0], -100); A.out[pb] = max(redB[0], -100); }
+}
+
+void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream)
+{
+    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16>), dim3(blocks), dim3(256), 0, stream, args);
+    else         hipLaunchKernelGGL((psa_score_bands_kernel<8>), dim3(blocks), dim3(256), 0, stream, args);
+}
+
+void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t stream)
+{
+    if (R == 16) hipLaunchKernelGGL((psa_score_bands_finish_kernel<16>), dim3((unsigned)args.b.packed_couples), dim3(256), 0, stream, args);
+    else         hipLaunchKernelGGL((psa_score_bands_finish_kernel<8>), dim3((unsigned)args.b.packed_couples), dim3(256), 0, stream, args);
 }
 
 void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream)

@@ -39,7 +39,7 @@ struct TraceCouple {
     int  ja, jb;                    // indices into the job table
     int  band0;                     // first band among the bands of all couples of the group
     int  W, S_total;                // bands / steps per band of the couple
-    int* state;                     // [W][2R+8][64] packed per-lane state between tiles
+    int* state;                     // [W][packed_state_ints(R)][64] packed per-lane state between tiles
 };
 
 struct PsaTracePackedArgs {
@@ -49,6 +49,9 @@ struct PsaTracePackedArgs {
     int M, X, E, O;
     unsigned pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
 };
+
+// ints of per-lane state a packed band keeps between tiles: hl/fb[R], hd, hbot, ebot, cch, mxA, mxB, baseA, baseB, in_star, cch2
+constexpr int packed_state_ints(int R) { return 2 * R + 10; }
 
 constexpr int kPackedTraceR = 4;    // rows per lane of the packed trace fill (trace layout = TraceCfg<4>)
 void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream);
