@@ -36,6 +36,26 @@ def config2(eng, reps=5):
             "valu_frac_at_10ops": P * L * L * 10 / (t * 1e-3) / 7.86432e13}
 
 
+def config5m(eng, P=128, L=50_000, reps=2):
+    """Not a BASELINE config: the config #5 pair shape in a batch far too small for one wave per couple (K1b)."""
+    dev = torch.device("cuda", 0)
+    seqs, off1, len1, off2, len2 = make_shard(P, L, 78, dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    prm = tsta_amd.Params()
+    ms = []
+    with torch.cuda.stream(st):
+        for i in range(reps + 1):
+            eng.psa_score_batch_dev(prm, P, seqs.data_ptr(), off1.data_ptr(), len1.data_ptr(), off2.data_ptr(),
+                                    len2.data_ptr(), scores.data_ptr(), L, st.cuda_stream)
+            k, nl = eng.last_kernel_ms()
+            if i:
+                ms.append(k)
+    t = float(np.median(ms))
+    return {"config": "#5 shape, only %d pairs of %d x %d, score only (band pipeline K1b)" % (P, L, L), "kernel_ms": t,
+            "launches": nl, "gcups": P * L * L / t / 1e6}
+
+
 def config3(eng):
     x = util.random_dna(777, 100_000); y = util.mutate(x, 778, 0.05)
     eng.psa_align(x[:3000], y[:3000])                       # warm-up (allocations are per-size, this only pages code in)
@@ -114,6 +134,8 @@ if __name__ == "__main__":
         print(json.dumps(config2(eng)), flush=True)
     if "3" in which:
         print(json.dumps(config3(eng)), flush=True)
+    if "5m" in which:
+        print(json.dumps(config5m(eng, int(os.environ.get("TSTA_BENCH_MID_PAIRS", 128)))), flush=True)
     if "5t" in which:
         print(json.dumps(config5t(eng, int(os.environ.get("TSTA_BENCH_ALIGN_PAIRS", 64)))), flush=True)
     if "4" in which:
