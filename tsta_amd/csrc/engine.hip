@@ -89,6 +89,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     e->device = device;
     if (const char* v = getenv("TSTA_PSA_PACKED")) e->opt_psa_packed = atoi(v);
     if (const char* v = getenv("TSTA_PSA_ELIDE")) e->opt_psa_elide = atoi(v) != 0;
+    if (const char* v = getenv("TSTA_TRACE_PERSISTENT")) e->opt_trace_persistent = atoi(v) != 0;
     if (const char* v = getenv("TSTA_TRACE_STREAMS")) e->opt_trace_streams = atoi(v);
     if (const char* v = getenv("TSTA_PSA_BANDS")) e->opt_psa_bands = atoi(v);
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
@@ -166,6 +167,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
     if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
     if (!strcmp(key, "psa_elide") && (v == 0 || v == 1)) { e->opt_psa_elide = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_persistent") && (v == 0 || v == 1)) { e->opt_trace_persistent = v; return TSTA_OK; }
     if (!strcmp(key, "trace_streams") && (v == 0 || v == 1)) { e->opt_trace_streams = v; return TSTA_OK; }
     if (!strcmp(key, "trace_packed") && (v == 0 || v == 1)) { e->opt_trace_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_bands") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_bands = (int)v; return TSTA_OK; }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
 }
 
-template <int R, bool PRED, bool TRACE>
+template <int R, bool PRED, bool TRACE, bool WT = false>
 __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                             const int M, const int X, const int E, const int O, uint4* __restrict__ tq)
 {
@@ -128,18 +128,44 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
             else if constexpr (R == 4) { acc[q] = tb[0]; }
             else { acc[(q * R) / 4] = (tb[0] << (8 * ((q * R) % 4))) + acc[(q * R) / 4]; }
         }
-        if (TRACE) tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
-                                                   (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
+        if (TRACE) {
+            const uint4 v = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
+                                       (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
+            if (WT) {
+                // write-through (system-scope) stores: no dirty trace lines for the persistent form's release fences to flush
+                unsigned long long* q = reinterpret_cast<unsigned long long*>(&tq[(size_t)g * 64]);
+                __hip_atomic_store(q, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(q + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                tq[(size_t)g * 64] = v;
+            }
+        }
     }
 }
 
-template <int R, bool TRACE>
+// PERSIST = false: one tile of the launch-per-diagonal pipeline (see file header).
+// PERSIST = true: ONE launch for the whole fill.  A wave draws a ticket = its band (bands of a job are consecutive),
+// sweeps all its steps, and before each 64-step block waits until the band above has published the bottom-row entries
+// the block reads (progress[g-1] >= t0 + 128: the upper band's lane 63 trails its lane 0 by 63 columns and stores a
+// block's captures at the block's end).  Tickets are drawn in band order by waves that are already running, so the
+// band a wave waits for is held by a wave that started earlier and needs nothing from later ones: no deadlock,
+// whatever the number of resident waves.  Hand-off = global stores, agent-scope fence, relaxed atomic store of the
+// progress word; the reader polls it with s_sleep, then fences before loading.  A poll that does not end within
+// ~2^22 sleeps sets status[0] and goes on (garbage, reported by the host) so that every wave always terminates.
+template <int R, bool TRACE, bool PERSIST>
 __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
 {
     constexpr int NS = TraceCfg<R>::NS;
     constexpr int SPB = TraceCfg<R>::SPB;
     const int lane = threadIdx.x & 63;
-    const int g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int g;
+    if (PERSIST) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(A.ticket, 1u);
+        g = (int)__builtin_amdgcn_readfirstlane(ticket);
+    } else {
+        g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    }
     if (g >= A.g_hi) return;
     int lo = 0, hi = A.n_jobs - 1;              // job = last one whose first band is <= g
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.jobs[mid].band0 <= g) lo = mid; else hi = mid - 1; }
@@ -150,6 +176,7 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     int s0 = A.d * A.T - shift, s1 = (A.d + 1) * A.T - shift;
     s0 = max(0, min(s0, J.S_total));
     s1 = max(0, min(s1, J.S_total));
+    if (PERSIST) { s0 = 0; s1 = J.S_total; }
     if (s0 >= s1) return;
 
     const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O;
@@ -183,15 +210,30 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
 
     for (int t0 = s0; t0 < s1; t0 += 64) {
+        if (PERSIST && w > 0) {
+            const int need = min(t0 + 128, J.S_total);
+            int spins = 0;
+            while (__hip_atomic_load(&A.progress[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { if (lane == 0) atomicOr(A.status, 1u); break; }
+                // once any wave has given up, nobody waits any more: the launch drains quickly
+                if ((spins & 255) == 0 && __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            }
+            __threadfence();                       // acquire: the upper band's rows are visible from here on
+        }
         const int c = t0 + lane;
         int2 nt = make_int2(0, 0); int na = 0;
         if (c < n) { nt = top[c]; na = seq_a[c]; }
         s.th = nt.x; s.te = nt.y; s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
-        if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq);
-        else                         trace_block<R, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else                         trace_block<R, true, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
         const int cs = t0 - 64 + lane;
         if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
+        if (PERSIST) {
+            __threadfence();                       // release: bottom-row entries before the progress word
+            if (lane == 0) __hip_atomic_store(&A.progress[g], t0 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = s.hl[k]; st[(2 * k + 1) * 64] = s.fb[k]; }
@@ -435,7 +477,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     if ((rc = e->reserve(e->in_seqs, seq_b, "hipMalloc(seqs)")) ||
         (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
         (rc = e->reserve(e->scratch, state_b + 256, "hipMalloc(state)")) ||
-        (rc = e->reserve(e->in_meta, jobs_b + couples_b + (size_t)n_jobs * 8 * sizeof(int) + 256, "hipMalloc(jobs)")) ||
+        (rc = e->reserve(e->in_meta, jobs_b + couples_b + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256 +
+                                         ((size_t)single_bands + 64) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
         (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
         (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
@@ -448,6 +491,9 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     TraceJob* d_singles = d_jobs + n_jobs;
     TraceCouple* d_couples = reinterpret_cast<TraceCouple*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b);
     int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b + couples_b);
+    // persistent K2: [0] ticket, [1] status, [64 ...] steps completed per band
+    int* d_sync = reinterpret_cast<int*>(reinterpret_cast<char*>(d_out) + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256);
+    const bool persistent = n_singles > 0 && e->opt_trace_persistent != 0;
     int sband0 = 0, cband0 = 0, max_n = 0;
     std::vector<TraceJob> singles;
     for (int j = 0; j < n_jobs; ++j) {
@@ -485,6 +531,9 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
 
     PsaTraceArgs A;
     A.jobs = d_singles; A.n_jobs = n_singles; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
+    A.ticket = reinterpret_cast<unsigned*>(d_sync); A.status = reinterpret_cast<unsigned*>(d_sync + 1); A.progress = d_sync + 64;
+    if (persistent && (rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)single_bands + 64) * sizeof(int), s), "hipMemsetAsync(sync)")))
+        return rc;
     PsaTracePackedArgs B;
     B.jobs = d_jobs; B.couples = d_couples; B.n_couples = n_couples; B.T = T; B.M = p->M; B.X = p->X; B.E = p->E; B.O = p->O;
     {
@@ -527,7 +576,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     }
     // band w of a job may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
     int64_t D = 0;
-    for (const TraceJob& J : singles) D = std::max<int64_t>(D, ((int64_t)J.S_total + (int64_t)(J.W - 1) * (T + 64) + T - 1) / T);
+    if (!persistent) for (const TraceJob& J : singles) D = std::max<int64_t>(D, ((int64_t)J.S_total + (int64_t)(J.W - 1) * (T + 64) + T - 1) / T);
     for (const TraceCouple& C : tc) D = std::max<int64_t>(D, ((int64_t)C.S_total + (int64_t)(C.W - 1) * (T + 64) + T - 1) / T);
     // range of bands with work in launch d: S_w(d) > 0 and S_w(d-1) < S_total
     auto active = [&](int64_t d, int W, int S_total, int band0, int64_t& g_lo, int64_t& g_hi) {
@@ -537,12 +586,17 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if (w_lo >= w_hi) return;
         g_lo = std::min(g_lo, band0 + w_lo); g_hi = std::max(g_hi, band0 + w_hi);
     };
+    if (persistent) {                                           // the singles' whole fill in one launch (flag hand-off)
+        A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
+        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
+        ++launches;
+    }
     for (int64_t d = 0; d < D; ++d) {
         int64_t g_lo = single_bands, g_hi = 0;
-        for (const TraceJob& J : singles) active(d, J.W, J.S_total, J.band0, g_lo, g_hi);
+        if (!persistent) for (const TraceJob& J : singles) active(d, J.W, J.S_total, J.band0, g_lo, g_hi);
         if (g_lo < g_hi) {
             A.d = (int)d; A.g_lo = (int)g_lo; A.g_hi = (int)g_hi;
-            hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE>), dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, s, A);
+            hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, false>), dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, s, A);
             ++launches;
         }
         for (int q = 0; q < n_chunks; ++q) {
@@ -571,6 +625,11 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     if ((rc = e->check(hipMemcpyAsync(h_out.data(), d_out, h_out.size() * sizeof(int), hipMemcpyDeviceToHost, s), "D2H out")) ||
         (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
         return rc;
+    if (persistent) {
+        unsigned st = 0;
+        if ((rc = e->check(hipMemcpy(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost), "D2H status"))) return rc;
+        if (st) { e->set_error("persistent trace fill: a band waited too long for the band above (status %u)", st); return TSTA_ERR_INTERNAL; }
+    }
     for (int j = 0; j < n_jobs; ++j) {
         jobs[j].maxscore = h_out[8 * j]; jobs[j].end_score = h_out[8 * j + 1];
         if (!TRACE) continue;

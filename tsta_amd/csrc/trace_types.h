@@ -26,6 +26,8 @@ struct PsaTraceArgs {
     int g_lo, g_hi;                 // range of group-wide band indices this launch covers
     int T, d;                       // tile length (steps), launch index
     int M, X, E, O;
+    // persistent form (one launch, flag hand-off between bands): ticket word, steps completed per band, error bits
+    unsigned* ticket; int* progress; unsigned* status;
 };
 
 template <int R> struct TraceCfg {
