@@ -56,6 +56,29 @@ def config5m(eng, P=128, L=50_000, reps=2):
             "launches": nl, "gcups": P * L * L / t / 1e6}
 
 
+def config5h(eng, P=8192, L=50_000):
+    """The bench.py shard through the HOST-pointer entry point: H2D of the sequences + kernels + D2H of the scores."""
+    import ctypes as C
+    dev = torch.device("cuda", 0)
+    seqs, off1, len1, off2, len2 = make_shard(P, L, 1000, dev)
+    h_seqs = seqs.cpu().numpy(); h_o1 = off1.cpu().numpy(); h_l1 = len1.cpu().numpy(); h_o2 = off2.cpu().numpy(); h_l2 = len2.cpu().numpy()
+    del seqs
+    torch.cuda.empty_cache()
+    out = np.zeros(P, dtype=np.int32)
+    prm = tsta_amd.Params()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    wall = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rc = tsta_amd.lib().tsta_psa_score_batch(eng._h, C.byref(prm), P, ptr(h_seqs), h_seqs.size, ptr(h_o1), ptr(h_l1), ptr(h_o2), ptr(h_l2), ptr(out))
+        wall.append(time.perf_counter() - t0)
+        assert rc == 0
+    k, _ = eng.last_kernel_ms()
+    return {"config": "#5 shard (8192 x 50 kbp^2) through tsta_psa_score_batch (host pointers, pageable memory): H2D + kernels + D2H",
+            "wall_ms_first": wall[0] * 1e3, "wall_ms": wall[1] * 1e3, "kernel_ms": k, "gcups_wall": P * float(L) * L / wall[1] / 1e9,
+            "gcups_kernel": P * float(L) * L / k / 1e6, "h2d_bytes": int(h_seqs.size)}
+
+
 def config3(eng):
     x = util.random_dna(777, 100_000); y = util.mutate(x, 778, 0.05)
     eng.psa_align(x[:3000], y[:3000])                       # warm-up (allocations are per-size, this only pages code in)
@@ -134,6 +157,8 @@ if __name__ == "__main__":
         print(json.dumps(config2(eng)), flush=True)
     if "3" in which:
         print(json.dumps(config3(eng)), flush=True)
+    if "5h" in which:
+        print(json.dumps(config5h(eng)), flush=True)
     if "5m" in which:
         print(json.dumps(config5m(eng, int(os.environ.get("TSTA_BENCH_MID_PAIRS", 128)))), flush=True)
     if "5t" in which:
