@@ -85,6 +85,20 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
                              const int64_t* d_off1, const int32_t* d_len1, const int64_t* d_off2,
                              const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream);
 
+/* 2-bit packed input for pure-ACGT batches: a quarter of the host memory, PCIe traffic and input
+ * HBM of the byte form.  Every sequence starts on a byte boundary of `packed`; 4 bases per byte, base i of a sequence in
+ * bits 2(i%4)..2(i%4)+1 of its byte i/4; codes A 0, C 1, T 2, G 3 (= (ASCII >> 1) & 3).  boff1/boff2 = BYTE offset of
+ * each sequence's first packed byte, len1/len2 = lengths in BASES.  The engine unpacks on the device (one pass) and
+ * runs the same kernels; results are those of the byte form on the corresponding ASCII sequences.
+ * tsta_pack_2bit packs n ASCII bases into (n+3)/4 bytes; TSTA_ERR_UNSUPPORTED if a byte is not one of A C G T. */
+int tsta_pack_2bit(const uint8_t* src, int64_t n, uint8_t* dst);
+int tsta_psa_score_batch_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* packed,
+                              int64_t packed_bytes, const int64_t* boff1, const int32_t* len1,
+                              const int64_t* boff2, const int32_t* len2, int32_t* out);
+int tsta_psa_score_batch_dev_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_packed,
+                                  const int64_t* d_boff1, const int32_t* d_len1, const int64_t* d_boff2,
+                                  const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PSA with traceback  ==  TSTA_psa: fill with back/eback/fback (psa.c:294-327,358-362) + trace()
  * (psa.c:435-518) for one pair.  Returns the printed maxsorce and the two gapped rows exactly as the

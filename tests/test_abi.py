@@ -52,3 +52,18 @@ def test_product_does_not_import_oracle():
                     with open(os.path.join(dp, fn), errors="ignore") as f:
                         body = f.read()
                     assert "liboracle" not in body and "oracle/" not in body and "oracle_psa" not in body, (dp, fn)
+
+
+def test_pack_2bit_is_a_host_function():
+    # tsta_pack_2bit needs no GPU: 4 bases per byte, base i in bits 2(i%4), codes A 0, C 1, T 2, G 3
+    import ctypes as C
+    import numpy as np
+    lib = tsta_amd.lib()
+    src = np.frombuffer(b"ACGTTGCAAC", dtype=np.uint8)
+    dst = np.zeros(3, dtype=np.uint8)
+    assert lib.tsta_pack_2bit(src.ctypes.data_as(C.c_void_p), len(src), dst.ctypes.data_as(C.c_void_p)) == 0
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    want = [sum(code[ch] << (2 * j) for j, ch in enumerate("ACGTTGCAAC"[i:i + 4])) for i in range(0, 10, 4)]
+    assert dst.tolist() == want
+    bad = np.frombuffer(b"ACNT", dtype=np.uint8)
+    assert lib.tsta_pack_2bit(bad.ctypes.data_as(C.c_void_p), 4, dst.ctypes.data_as(C.c_void_p)) == -5      # TSTA_ERR_UNSUPPORTED

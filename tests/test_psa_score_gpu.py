@@ -403,3 +403,16 @@ def test_band_pipeline_few_long_pairs(eng):
     got = eng.psa_score_batch(pairs)
     want = util.oracle_maxscore_batch(pairs)
     assert np.array_equal(got, want)
+
+
+def test_2bit_packed_input(eng):
+    # tsta_psa_score_batch_2bit: same scores as the byte form on the same (pure ACGT) sequences; lengths that are not
+    # multiples of 4, empty sequences, a batch large enough for the packed kernel and one small enough for the band pipeline
+    e = np.zeros(0, dtype=np.uint8)
+    pairs = [(util.random_dna(70 + i, 1 + 37 * i), util.mutate(util.random_dna(70 + i, 1 + 37 * i), 170 + i, 0.1)) for i in range(40)]
+    pairs += [(e, util.random_dna(1, 9)), (util.random_dna(2, 5), e), (util.random_dna(3, 3001), util.random_dna(4, 2999))]
+    assert np.array_equal(eng.psa_score_batch_2bit(pairs), util.oracle_maxscore_batch(pairs))
+    big = [(util.random_dna(500 + i, 300 + i % 7), util.random_dna(900 + i, 290 + i % 5)) for i in range(1200)]
+    assert np.array_equal(eng.psa_score_batch_2bit(big), eng.psa_score_batch(big))
+    with pytest.raises(tsta_amd.TstaError):
+        eng.psa_score_batch_2bit([(np.frombuffer(b"ACGN", dtype=np.uint8), util.random_dna(1, 4))])

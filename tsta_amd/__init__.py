@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
     "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align", "tsta_psa_align_batch", "tsta_alignments_free",
+    "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit",
 ]
 
 
@@ -78,6 +79,10 @@ def lib():
         L.tsta_psa_score_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
         L.tsta_psa_score_batch_dev.restype = C.c_int
         L.tsta_psa_score_batch_dev.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.tsta_pack_2bit.restype = C.c_int
+        L.tsta_pack_2bit.argtypes = [vp, i64, vp]
+        L.tsta_psa_score_batch_2bit.restype = C.c_int
+        L.tsta_psa_score_batch_2bit.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
         L.tsta_psa_align_batch.restype = C.c_int
         L.tsta_psa_align_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, C.POINTER(Alignment)]
         L.tsta_alignments_free.restype = None
@@ -157,6 +162,29 @@ class Engine:
         rc = lib().tsta_psa_score_batch(self._h, C.byref(params), len(pairs), _ptr(sq), len(seqs), _ptr(o1), _ptr(l1),
                                         _ptr(o2), _ptr(l2), _ptr(out))
         self._check(rc, "tsta_psa_score_batch")
+        return out
+
+    def psa_score_batch_2bit(self, pairs, params=None):
+        """Like psa_score_batch for pure-ACGT pairs, handing the engine 2-bit packed sequences (4 bases per byte)."""
+        params = params or Params()
+        out = np.zeros(len(pairs), dtype=np.int32)
+        if len(pairs) == 0:
+            return out
+        chunks, b1, l1, b2, l2 = [], [], [], [], []
+        pos = 0
+        for a, b in pairs:
+            for seq, bo, ln in ((a, b1, l1), (b, b2, l2)):
+                seq = np.ascontiguousarray(np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else seq, dtype=np.uint8)
+                dst = np.zeros((len(seq) + 3) // 4, dtype=np.uint8)
+                rc = lib().tsta_pack_2bit(_ptr(seq if len(seq) else np.zeros(1, np.uint8)), len(seq), _ptr(dst if len(dst) else np.zeros(1, np.uint8)))
+                self._check(rc, "tsta_pack_2bit")
+                bo.append(pos); ln.append(len(seq)); chunks.append(dst); pos += len(dst)
+        packed = np.concatenate(chunks) if pos else np.zeros(1, dtype=np.uint8)
+        b1 = np.array(b1, dtype=np.int64); l1 = np.array(l1, dtype=np.int32)
+        b2 = np.array(b2, dtype=np.int64); l2 = np.array(l2, dtype=np.int32)
+        rc = lib().tsta_psa_score_batch_2bit(self._h, C.byref(params), len(pairs), _ptr(packed), pos, _ptr(b1), _ptr(l1),
+                                             _ptr(b2), _ptr(l2), _ptr(out))
+        self._check(rc, "tsta_psa_score_batch_2bit")
         return out
 
     def psa_score_batch_dev(self, params, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream=0):

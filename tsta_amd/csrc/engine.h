@@ -34,6 +34,7 @@ struct Engine {
     DevBuf trace;        // packed trace matrix (tsta_psa_align) / POA trace arrays
     DevBuf scratch;
     DevBuf scratch2;
+    DevBuf unpacked;     // ASCII copy of 2-bit packed input (tsta_psa_score_batch*_2bit)
     DevBuf pair_flags;   // per-pair alphabet flags of the packed score kernel
 
     void set_error(const char* fmt, ...);

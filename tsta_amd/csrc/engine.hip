@@ -145,7 +145,7 @@ void tsta_engine_destroy(tsta_engine* eng)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
-                            &e->scratch2, &e->pair_flags}) {
+                            &e->scratch2, &e->pair_flags, &e->unpacked}) {
         if (b->p) (void)hipFree(b->p);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);

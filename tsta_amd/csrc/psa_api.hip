@@ -107,6 +107,33 @@ __global__ __launch_bounds__(256) void psa_alphabet_flags_kernel(const uint8_t* 
     }
 }
 
+// 2-bit packed input (tsta_psa_score_batch*_2bit): sequence q (q = 2k: -1 sequence of pair k, 2k+1: its -2 sequence)
+// starts at byte boff[q] of `packed`, 4 bases per byte, base i in bits 2(i%4)..2(i%4)+1 of byte i/4, codes
+// A 0, C 1, T 2, G 3 (= (ASCII >> 1) & 3).  Unpacked to ASCII at stride-sized slots of `out`; also writes the byte
+// offsets the batch kernels index with.  One block per sequence (grid-stride).
+__global__ __launch_bounds__(256) void psa_unpack_2bit_kernel(const uint8_t* __restrict__ packed, const int64_t* boff1, const int32_t* len1,
+                                                              const int64_t* boff2, const int32_t* len2, int64_t n_pairs, int64_t stride,
+                                                              uint8_t* __restrict__ out, int64_t* off1, int64_t* off2)
+{
+    for (int64_t q = blockIdx.x; q < 2 * n_pairs; q += gridDim.x) {
+        const int64_t k = q >> 1;
+        const uint8_t* src = packed + ((q & 1) ? boff2[k] : boff1[k]);
+        const int n = (q & 1) ? len2[k] : len1[k];
+        uint8_t* dst = out + q * stride;
+        if (threadIdx.x == 0) { if (q & 1) off2[k] = q * stride; else off1[k] = q * stride; }
+        // one packed byte -> one aligned 32-bit word of ASCII (stride is a multiple of 16); the tail word may run past
+        // n inside the slot, which is padding
+        uint32_t* dw = reinterpret_cast<uint32_t*>(dst);
+        for (int i = threadIdx.x; i < (n + 3) / 4; i += blockDim.x) {
+            const uint32_t b = src[i];
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= (uint32_t)((0x47544341u >> (8 * ((b >> (2 * j)) & 3u))) & 0xffu) << (8 * j);   // "ACTG"
+            dw[i] = w;
+        }
+    }
+}
+
 // geometry key of a pair: (columns n = longer sequence) << 32 | (rows m = shorter)
 __global__ void psa_geometry_keys_kernel(const int32_t* len1, const int32_t* len2, int64_t n_pairs, uint64_t* keys, uint32_t* idx)
 {
@@ -325,6 +352,89 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     if (rc != TSTA_OK) return rc;
     if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
     return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
+}
+
+
+int tsta_pack_2bit(const uint8_t* src, int64_t n, uint8_t* dst)
+{
+    if (n < 0 || (n && (!src || !dst))) return TSTA_ERR_INVALID_ARG;
+    for (int64_t i = 0; i < n; i += 4) {
+        uint8_t b = 0;
+        for (int j = 0; j < 4 && i + j < n; ++j) {
+            const uint8_t c = src[i + j];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return TSTA_ERR_UNSUPPORTED;
+            b |= (uint8_t)(((c >> 1) & 3u) << (2 * j));
+        }
+        dst[i / 4] = b;
+    }
+    return TSTA_OK;
+}
+
+int tsta_psa_score_batch_dev_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_packed,
+                                  const int64_t* d_boff1, const int32_t* d_len1, const int64_t* d_boff2,
+                                  const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
+{
+    if (!eng || !p || n_pairs < 0 || max_len < 0) return TSTA_ERR_INVALID_ARG;
+    if (n_pairs == 0) return TSTA_OK;
+    if (!d_packed || !d_boff1 || !d_len1 || !d_boff2 || !d_len2 || !d_out) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
+    if (rc != TSTA_OK) return rc;
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+    const int64_t stride = ((int64_t)max_len + 15) / 16 * 16 + 16;
+    const size_t nb = (size_t)n_pairs;
+    if ((rc = e->reserve(e->unpacked, 2 * nb * (size_t)stride + 2 * nb * sizeof(int64_t) + 64, "hipMalloc(unpacked sequences)")) != TSTA_OK) return rc;
+    uint8_t* d_seqs = reinterpret_cast<uint8_t*>(e->unpacked.p);
+    int64_t* d_off1 = reinterpret_cast<int64_t*>(d_seqs + 2 * nb * (size_t)stride);
+    int64_t* d_off2 = d_off1 + nb;
+    hipLaunchKernelGGL(tsta::psa_unpack_2bit_kernel, dim3((unsigned)std::min<int64_t>(2 * n_pairs, 65536)), dim3(256), 0, s,
+                       d_packed, d_boff1, d_len1, d_boff2, d_len2, n_pairs, stride, d_seqs, d_off1, d_off2);
+    if ((rc = e->check(hipGetLastError(), "unpack launch")) != TSTA_OK) return rc;
+    return tsta_psa_score_batch_dev(eng, p, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream);
+}
+
+int tsta_psa_score_batch_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* packed,
+                              int64_t packed_bytes, const int64_t* boff1, const int32_t* len1,
+                              const int64_t* boff2, const int32_t* len2, int32_t* out)
+{
+    if (!eng || !p || n_pairs < 0 || packed_bytes < 0) return TSTA_ERR_INVALID_ARG;
+    if (n_pairs == 0) return TSTA_OK;
+    if (!packed || !boff1 || !len1 || !boff2 || !len2 || !out) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int32_t max_len = 0;
+    for (int64_t k = 0; k < n_pairs; ++k) {
+        if (len1[k] < 0 || len2[k] < 0 || boff1[k] < 0 || boff2[k] < 0 ||
+            boff1[k] + ((int64_t)len1[k] + 3) / 4 > packed_bytes || boff2[k] + ((int64_t)len2[k] + 3) / 4 > packed_bytes) {
+            e->set_error("pair %lld: packed sequence range outside packed[0..%lld)", (long long)k, (long long)packed_bytes);
+            return TSTA_ERR_INVALID_ARG;
+        }
+        max_len = std::max(max_len, std::max(len1[k], len2[k]));
+    }
+    int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
+    if (rc != TSTA_OK) return rc;
+    const size_t nb = (size_t)n_pairs;
+    std::vector<int64_t> h_off(2 * nb);
+    std::vector<int32_t> h_len(2 * nb);
+    for (size_t k = 0; k < nb; ++k) { h_off[k] = boff1[k]; h_off[nb + k] = boff2[k]; h_len[k] = len1[k]; h_len[nb + k] = len2[k]; }
+    const size_t meta_bytes = nb * (2 * sizeof(int64_t) + 2 * sizeof(int32_t));
+    if ((rc = e->reserve(e->in_seqs, (size_t)packed_bytes + 16, "hipMalloc(packed seqs)")) != TSTA_OK) return rc;
+    if ((rc = e->reserve(e->in_meta, meta_bytes, "hipMalloc(meta)")) != TSTA_OK) return rc;
+    if ((rc = e->reserve(e->out_scores, nb * sizeof(int32_t), "hipMalloc(scores)")) != TSTA_OK) return rc;
+    char* m = reinterpret_cast<char*>(e->in_meta.p);
+    int64_t* d_off1 = reinterpret_cast<int64_t*>(m);
+    int64_t* d_off2 = d_off1 + nb;
+    int32_t* d_len1 = reinterpret_cast<int32_t*>(d_off2 + nb);
+    int32_t* d_len2 = d_len1 + nb;
+    hipStream_t s = e->stream;
+    if ((rc = e->check(hipMemcpyAsync(e->in_seqs.p, packed, (size_t)packed_bytes, hipMemcpyHostToDevice, s), "H2D packed seqs")) ||
+        (rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
+        (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")))
+        return rc;
+    rc = tsta_psa_score_batch_dev_2bit(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+                                       d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
+    if (rc != TSTA_OK) return rc;
+    if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
+    return e->check(hipStreamSynchronize(s), "psa_score_batch_2bit sync");
 }
 
 }  // extern "C"
