@@ -58,6 +58,8 @@ void tsta_free(void* p);                                   /* frees host buffers
  *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline
+ *   "poa_skewed"       0 (default) | 1: POA fill with the lane-skewed band pipeline (experiment, slower; poa_fill_skewed.hip)
+ *   "trace_persistent" 0 (default) | 1: single-launch trace fill with flag hand-off (experiment, slower; psa_trace.hip)
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */
 int  tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value);

@@ -119,3 +119,26 @@ def test_on_device_walk_random_dags(eng):
         steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
         got = [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps]
         assert (got, end_col) == (want, want_end)
+
+
+def test_lane_skewed_fill_variant(eng):
+    # K4s (poa_fill_skewed.hip), an opt-in experiment: same trace arrays, lastscore, best sink and on-device walk as K4
+    # on every fixture (graphs outside its fast path silently run K4) and on sparse random DAGs that stay inside it
+    try:
+        eng.set_option("poa_skewed", 1)
+        for path in FIXTURES:
+            z, sc = load(path)
+            best, last, src, es, fs = eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"],
+                                                   tsta_amd.Params(**sc))
+            check_against_fixture(z, best, last, src, es, fs)
+            steps, end_col, _ = eng.poa_align(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"], tsta_amd.Params(**sc))
+            want_steps, want_end = util.poa_walk(z["pred_off"], z["pred"], z["is_sink"], last, src, es, fs)
+            assert end_col == want_end
+            assert [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps] == want_steps
+        for seed, V, extra, n in [(11, 300, 2, 500), (12, 900, 3, 1300), (13, 130, 2, 64), (14, 65, 1, 1)]:
+            pred_off, pred, base, is_sink, seq = random_dag(seed, V, extra, n)
+            got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+            want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
+    finally:
+        eng.set_option("poa_skewed", 0)

@@ -92,6 +92,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (const char* v = getenv("TSTA_TRACE_PERSISTENT")) e->opt_trace_persistent = atoi(v) != 0;
     if (const char* v = getenv("TSTA_TRACE_STREAMS")) e->opt_trace_streams = atoi(v);
     if (const char* v = getenv("TSTA_PSA_BANDS")) e->opt_psa_bands = atoi(v);
+    if (const char* v = getenv("TSTA_POA_SKEWED")) e->opt_poa_skewed = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
@@ -172,6 +173,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "trace_packed") && (v == 0 || v == 1)) { e->opt_trace_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_bands") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_bands = (int)v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
+    if (!strcmp(key, "poa_skewed") && (v == 0 || v == 1)) { e->opt_poa_skewed = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;

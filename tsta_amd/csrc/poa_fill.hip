@@ -28,31 +28,9 @@
 
 #include "../../include/tsta_engine.h"
 #include "engine.h"
+#include "poa_types.h"
 
 namespace tsta {
-
-constexpr int kNeg = -1000000000;
-// columns per lane KC = 4 (256-column tiles) or 2 (128-column tiles: more tiles in flight for short sequences)
-constexpr int kRB = 32;                  // graph nodes (rows) per tile; <= 64 (per-row side data lives one row per lane)
-
-struct PoaArgs {
-    int V, n;
-    const int* pred_off; const int* pred; const uint8_t* base; const uint8_t* is_sink;
-    const uint8_t* seq;                  // n bytes
-    const int* slot;                     // [V]: row slot of node r (slots are recycled once no later tile needs the row)
-    const int* pred_slot;                // parallel to pred[]: slot of that predecessor
-    int* Hrow;                           // [nslots][pitch]: Hrow[slot][c+3] = H(r,c), c = 0..n   (slot 0 = virtual init)
-    int* Erow;                           // [nslots][pitch]: Erow[slot][c]   = Eagg(r,c+1), c = 0..n-1
-    int64_t pitch;                       // ints per row, multiple of 4
-    int* carry;                          // [V][nchunks+1]: Fbar entering chunk q of row r
-    uint8_t* cflag;                      // [V][nchunks+1]: "F at the first column of chunk q is an open"
-    int nchunks, nrb, d, q_lo;           // launch d runs the tiles (q, rb = d - q)
-    int kc;                              // columns per lane of this run (2 or 4)
-    int8_t* source; int8_t* esource; int8_t* fsource; int64_t tpitch;   // [V][tpitch] device layout (tpitch mult. of 8)
-    int* lastscore;                      // [V]
-    int* best;                           // [0] = best sink
-    int M, X, E, O;
-};
 
 __device__ __forceinline__ int dpp_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
 
@@ -306,6 +284,7 @@ struct PoaWalkArgs {
     int V, n;
     const int* pred_off; const int* pred; const uint8_t* is_sink;
     const int8_t* source; const int8_t* esource; const int8_t* fsource; int64_t tpitch;
+    int skew;                            // 1: node r's column c is byte c + (r & 63) of its row (lane-skewed fill)
     const int* lastscore;
     tsta_poa_step* steps;                // out, capacity V + n + 2
     int* out;                            // out[0] = number of steps, out[1] = end column, out[2] = start node
@@ -330,7 +309,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 
     while (num1 != -1 && num2 != -1) {
         // stage the window whose lower-right region holds (num1, num2)
-        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
+        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - (A.skew ? 32 : 48)) & ~15);   // skewed rows: 49 usable columns per piece
         {
             const int rr = rw0 + lane;
             uint4 t[3][4];
@@ -339,7 +318,8 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const int64_t col = cw0 + 16 * x;
+                    // (skewed rows: the 64 bytes staged for row rr start at the aligned byte at or below its column cw0)
+                    const int64_t col = ((cw0 + (A.skew ? (rr & 63) : 0)) & ~15) + 16 * x;
                     t[a][x] = (rr < A.V && col < A.tpitch) ? *reinterpret_cast<const uint4*>(base + (size_t)rr * A.tpitch + col)
                                                             : make_uint4(0, 0, 0, 0);
                 }
@@ -352,14 +332,16 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         __syncthreads();
         const int8_t* wb = reinterpret_cast<const int8_t*>(win);
         auto rd = [&](int a, int row, int col) -> int {      // trace byte of array a at (row, col)
-            if (row >= rw0 && row < rw0 + 64 && col >= cw0 && col < cw0 + 64)
-                return wb[(a * 64 + (row - rw0)) * 64 + (col - cw0)];
+            const int sk = A.skew ? (row & 63) : 0;
+            const int off = col + sk - ((cw0 + sk) & ~15);     // byte of the staged 64-byte piece of this row
+            if (row >= rw0 && row < rw0 + 64 && off >= 0 && off < 64)
+                return wb[(a * 64 + (row - rw0)) * 64 + off];
             const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
-            return base[(size_t)row * A.tpitch + col];
+            return base[(size_t)row * A.tpitch + col + sk];
         };
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
-            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + 64) break;        // restage
+            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + (A.skew ? 49 : 64)) break;   // restage
             int code;
             if (forced >= 0) { code = forced; forced = -1; } else code = __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
             const int kind = code / 42, pidx = code % 42;
@@ -402,6 +384,18 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 
 namespace tsta {
 
+// plain [V][npl] copies of the three skewed trace arrays (tsta_poa_fill hands the arrays to the host)
+__global__ void poa_deskew_kernel(const int8_t* src, int64_t tpitch, int V, int n, int8_t* dst, int64_t npl, int r0)
+{
+    const int r = r0 + blockIdx.y, a = blockIdx.z;
+    const int8_t* sr = src + ((size_t)a * V + r) * tpitch + (r & 63);
+    int8_t* dr = dst + ((size_t)a * V + r) * npl;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) dr[c] = sr[c];
+}
+
+void launch_poa_init(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (A.n + 256) / 256)), dim3(256), 0, s, A); }
+void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A); }
+
 // Validation, uploads, workspace and the fill launches; leaves everything on the device.
 static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
                              bool want_trace, PoaArgs& A)
@@ -417,6 +411,13 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
+    A.skew = 0;
+    if (e->opt_poa_skewed != 0) {                            // K4s: lane-skewed band pipeline, when the graph fits its fast path
+        bool used = false;
+        if ((rc = poa_run_skewed(e, p, dag, seq, n, want_trace, A, &used)) != TSTA_OK) return rc;
+        if (used) return TSTA_OK;
+        A.skew = 0;
+    }
 
     // 4 columns per lane (256-column tiles) are cheaper per cell; 2 per lane put twice as many tiles in flight,
     // which wins while the sequence is short enough that the tile wavefront is the limit
@@ -533,7 +534,18 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     int h_best = -1;
     if ((rc = e->check(hipMemcpyAsync(&h_best, A.best, 4, hipMemcpyDeviceToHost, s), "D2H best"))) return rc;
     if (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) return rc;
-    if (want_trace) {
+    if (want_trace && A.skew) {
+        const int64_t npl = ((int64_t)n + 15) / 16 * 16;
+        if ((rc = e->reserve(e->scratch2, 3 * (size_t)V * npl + 64, "hipMalloc(plain trace)"))) return rc;
+        int8_t* pl = reinterpret_cast<int8_t*>(e->scratch2.p);
+        for (int r0 = 0; r0 < V; r0 += 65535)
+            hipLaunchKernelGGL(poa_deskew_kernel, dim3(std::min(16, (n + 255) / 256), (unsigned)std::min(65535, V - r0), 3), dim3(256), 0, s,
+                               A.source, A.tpitch, V, n, pl, npl, r0);
+        if ((rc = e->check(hipMemcpy2DAsync(source, n, pl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
+            (rc = e->check(hipMemcpy2DAsync(esource, n, pl + (size_t)V * npl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
+            (rc = e->check(hipMemcpy2DAsync(fsource, n, pl + 2 * (size_t)V * npl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
+            return rc;
+    } else if (want_trace) {
         if ((rc = e->check(hipMemcpy2DAsync(source, n, A.source, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
             (rc = e->check(hipMemcpy2DAsync(esource, n, A.esource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
             (rc = e->check(hipMemcpy2DAsync(fsource, n, A.fsource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
@@ -562,7 +574,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)"))) return rc;
     PoaWalkArgs Wk;
     Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink;
-    Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch;
+    Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch; Wk.skew = A.skew;
     Wk.lastscore = A.lastscore;
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
     Wk.out = A.best + 4;

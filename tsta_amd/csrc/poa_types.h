@@ -1,0 +1,48 @@
+// poa_types.h — arguments shared by the POA fill kernels (poa_fill.hip: tile wavefront; poa_fill_skewed.hip: lane-skewed
+// band pipeline), the best-sink reduction and the walker.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct tsta_params;
+struct tsta_dag_csr;
+
+namespace tsta {
+
+struct Engine;
+
+constexpr int kNeg = -1000000000;
+// columns per lane KC = 4 (256-column tiles) or 2 (128-column tiles: more tiles in flight for short sequences)
+constexpr int kRB = 32;                  // graph nodes (rows) per tile; <= 64 (per-row side data lives one row per lane)
+
+struct PoaArgs {
+    int V, n;
+    const int* pred_off; const int* pred; const uint8_t* base; const uint8_t* is_sink;
+    const uint8_t* seq;                  // n bytes
+    const int* slot;                     // [V]: row slot of node r (slots are recycled once no later tile needs the row)
+    const int* pred_slot;                // parallel to pred[]: slot of that predecessor
+    int* Hrow;                           // [nslots][pitch]: Hrow[slot][c+3] = H(r,c), c = 0..n   (slot 0 = virtual init)
+    int* Erow;                           // [nslots][pitch]: Erow[slot][c]   = Eagg(r,c+1), c = 0..n-1
+    int64_t pitch;                       // ints per row, multiple of 4
+    int* carry;                          // [V][nchunks+1]: Fbar entering chunk q of row r
+    uint8_t* cflag;                      // [V][nchunks+1]: "F at the first column of chunk q is an open"
+    int nchunks, nrb, d, q_lo;           // launch d runs the tiles (q, rb = d - q)
+    int kc;                              // columns per lane of this run (2 or 4)
+    int8_t* source; int8_t* esource; int8_t* fsource; int64_t tpitch;   // [V][tpitch] device layout (tpitch mult. of 8)
+    int* lastscore;                      // [V]
+    int* best;                           // [0] = best sink
+    int M, X, E, O;
+    int skew;                            // 1: row r's column c lives at index c + (r & 63) of Hrow/Erow/trace rows (lane-skewed fill)
+};
+
+
+void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
+void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
+
+// poa_fill_skewed.hip: the lane-skewed fill.  Returns TSTA_OK and sets *used = true when it ran (A is then complete and
+// the trace arrays / H rows are in the SKEWED layout, A.skew = 1); *used = false when the graph does not fit its
+// fast path (in-degree > 4 or too many non-backbone predecessors in one 64-node band) and the tile kernel must run.
+int poa_run_skewed(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
+                   bool want_trace, PoaArgs& A, bool* used);
+
+}  // namespace tsta

@@ -3,6 +3,7 @@
  * (tsta_poa_fill); graph fusion, topological sorting and the result writer are host C (poa_graph.c). */
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "../../include/tsta_engine.h"
@@ -21,7 +22,9 @@ static void print_usage(void)
     printf("example:\n./TSTA_msa -i seq.fa -o output.txt\n");
 }
 
-typedef struct gpu_ctx { tsta_engine* eng; tsta_params prm; } gpu_ctx;
+typedef struct gpu_ctx { tsta_engine* eng; tsta_params prm; double gpu_s; } gpu_ctx;
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static int gpu_fill(void* vctx, int n_nodes, const int32_t* pred_off, const int32_t* pred, const uint8_t* base,
                     const uint8_t* is_sink, const uint8_t* seq, int32_t n, int8_t* source, int8_t* esource,
@@ -30,7 +33,9 @@ static int gpu_fill(void* vctx, int n_nodes, const int32_t* pred_off, const int3
     gpu_ctx* c = (gpu_ctx*)vctx;
     tsta_dag_csr dag = { n_nodes, pred_off, pred, base, is_sink };
     int32_t best = -1;
+    const double t0 = now_s();
     int rc = tsta_poa_fill(c->eng, &c->prm, &dag, seq, n, source, esource, fsource, lastscore, &best);
+    c->gpu_s += now_s() - t0;
     if (rc != TSTA_OK) fprintf(stderr, "tsta_poa_fill: %s: %s\n", tsta_strerror(rc), tsta_last_error(c->eng));
     return rc;
 }
@@ -45,7 +50,9 @@ static int gpu_path(void* vctx, int n_nodes, const int32_t* pred_off, const int3
     gpu_ctx* c = (gpu_ctx*)vctx;
     tsta_dag_csr dag = { n_nodes, pred_off, pred, base, is_sink };
     tsta_poa_step* st = NULL;
+    const double t0 = now_s();
     int rc = tsta_poa_align(c->eng, &c->prm, &dag, seq, n, &st, n_steps, end_col, NULL);
+    c->gpu_s += now_s() - t0;
     if (rc != TSTA_OK) fprintf(stderr, "tsta_poa_align: %s: %s\n", tsta_strerror(rc), tsta_last_error(c->eng));
     *steps = (pg_step*)st;
     *free_steps = free_gpu_steps;
@@ -54,7 +61,8 @@ static int gpu_path(void* vctx, int n_nodes, const int32_t* pred_off, const int3
 
 int main(int argc, char* argv[])
 {
-    gpu_ctx ctx = { NULL, { 2, -5, -2, -4 } };
+    gpu_ctx ctx = { NULL, { 2, -5, -2, -4 }, 0.0 };
+    const double t_start = now_s();
     const char *input = NULL, *output = "output.txt";
     int c;
     while ((c = getopt(argc, argv, "M:X:E:O:T:W:i:o:")) != -1) {
@@ -78,9 +86,13 @@ int main(int argc, char* argv[])
     const char* dev = getenv("TSTA_DEVICE");
     int rc = tsta_engine_create(dev ? atoi(dev) : 0, &ctx.eng);
     if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
+    const double t_init = now_s();
     /* default: the walk runs on the GPU next to the trace arrays; TSTA_MSA_HOST_WALK=1 copies the arrays back instead */
     if (getenv("TSTA_MSA_HOST_WALK")) rc = msa_run(input, output, gpu_fill, NULL, &ctx);
     else                              rc = msa_run(input, output, NULL, gpu_path, &ctx);
+    if (getenv("TSTA_MSA_TIMING"))      /* diagnostics only: where the wall time of this run went */
+        fprintf(stderr, "[tsta] engine create %.3f s, GPU fill+walk calls %.3f s, host (FASTA, graph fusion, sorts, writer) %.3f s\n",
+                t_init - t_start, ctx.gpu_s, now_s() - t_init - ctx.gpu_s);
     tsta_engine_destroy(ctx.eng);
     return rc ? 1 : 0;
 }
