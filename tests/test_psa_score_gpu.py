@@ -142,7 +142,8 @@ def test_packed_couples_equal_geometry(eng, scoring):
 
 
 @pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=3, X=-1, E=0, O=-7),
-                                     dict(M=4, X=-6, E=-3, O=-5), dict(M=2, X=-5, E=-9, O=-1)])
+                                     dict(M=4, X=-6, E=-3, O=-5), dict(M=2, X=-5, E=-9, O=-1),
+                                     dict(M=3, X=-4, E=-3, O=-4)])          # R=32 with the elided frame 600 below the 16-bit bound
 def test_packed_max_elision(eng, scoring):
     # Blocks whose entering scores prove that maxsorce cannot rise there run without the running max, in a row-shifted
     # frame (psa_score_packed.hip: pstep_elided).  The decision is data dependent: cover maxima reached early, late,
@@ -357,10 +358,15 @@ def test_fuzz_packed_vs_int32_vs_oracle(eng):
             assert np.array_equal(res[0], res[32]), (trial, M, X, E, O)
             assert np.array_equal(res[0], res[16]), (trial, M, X, E, O)
             assert np.array_equal(res[0], res[8]), (trial, M, X, E, O)
+            eng.set_option("psa_packed", -1)
+            for bands in (8, 16):                      # K1b, the band pipeline, forced
+                eng.set_option("psa_bands", bands)
+                assert np.array_equal(res[0], eng.psa_score_batch(pairs, prm)), (trial, bands, M, X, E, O)
+            eng.set_option("psa_bands", -1)
             if trial % 8 == 0:
                 assert np.array_equal(res[0], util.oracle_maxscore_batch(pairs, M=M, X=X, E=E, O=O)), (trial, M, X, E, O)
     finally:
-        eng.set_option("psa_packed", -1)
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1)
 
 
 @pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=4, X=-6, E=-3, O=-5),

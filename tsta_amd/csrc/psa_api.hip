@@ -189,7 +189,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     // ---- K1b first: a batch too small to fill the chip with one wave per couple runs the bands of every couple
     // concurrently (band pipeline, one launch per tile diagonal)
     size_t bands_rows = 0;
-    const int Rb = e->opt_psa_packed > 0 ? 0 : tsta::psa_bands_rows_per_lane(*p, n_pairs / 2, max_len, e->n_cu, e->opt_psa_bands, &bands_rows);
+    const int Rb = (e->opt_psa_packed >= 0 && e->opt_psa_bands <= 0) ? 0 : tsta::psa_bands_rows_per_lane(*p, n_pairs / 2, max_len, e->n_cu, e->opt_psa_bands, &bands_rows);
     const bool enough = (n_pairs > (int64_t)e->n_cu * 4 || e->opt_psa_packed > 0) && !Rb;
     const int Rp = enough ? tsta::psa_packed_rows_per_lane(*p, n_pairs / 2, e->opt_psa_packed, max_len) : 0;
     const int64_t couples = (Rp || Rb) ? n_pairs / 2 : 0;
