@@ -45,6 +45,10 @@ int  tsta_device_count(void);                              /* <0: tsta_status */
 int  tsta_engine_create(int device, tsta_engine** out);
 void tsta_engine_destroy(tsta_engine* eng);
 void tsta_free(void* p);                                   /* frees host buffers returned by this library */
+/* An engine keeps its device workspaces between calls and only grows them (a 64-pair batch of 50 kbp alignments holds
+ * ~165 GB of trace).  This hands them back to the device; the next call allocates what it needs.  Waits for the
+ * engine's stream.  Do not call while a *_dev call of this engine is still in flight on another stream. */
+int  tsta_engine_release_workspaces(tsta_engine* eng);
 
 /* Tuning knobs (tests / experiments; results never depend on them).  Keys:
  *   "psa_packed"      -1 auto (default) | 0 never use the packed 16-bit kernel | 8 / 16 / 32 force it with that many rows per lane

@@ -216,6 +216,9 @@ def test_batch_full_size_50k_properties(eng):
         assert ms == oms and util.alignment_score(ra, rb) == oend
     one = eng.psa_align(*cases[0])
     assert one == res[0]
+    # the ~15 GB of trace this batch left in the engine can be handed back; the next call simply allocates again
+    eng.release_workspaces()
+    assert eng.psa_align(*cases[1]) == res[1]
 
 
 @pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=4, X=-6, E=-3, O=-5),

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "tsta_strerror", "tsta_last_error", "tsta_device_count", "tsta_engine_create", "tsta_engine_destroy",
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
     "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align", "tsta_psa_align_batch", "tsta_alignments_free",
-    "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit",
+    "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit", "tsta_engine_release_workspaces",
 ]
 
 
@@ -75,6 +75,7 @@ def lib():
         L.tsta_engine_destroy.restype = None; L.tsta_engine_destroy.argtypes = [vp]
         L.tsta_free.restype = None; L.tsta_free.argtypes = [vp]
         L.tsta_engine_set_option.restype = C.c_int; L.tsta_engine_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.tsta_engine_release_workspaces.restype = C.c_int; L.tsta_engine_release_workspaces.argtypes = [vp]
         L.tsta_psa_score_batch.restype = C.c_int
         L.tsta_psa_score_batch.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
         L.tsta_psa_score_batch_dev.restype = C.c_int
@@ -140,6 +141,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def release_workspaces(self):
+        """Hand the engine's device workspaces back to the device (they are re-allocated on demand)."""
+        self._check(lib().tsta_engine_release_workspaces(self._h), "tsta_engine_release_workspaces")
 
     def set_option(self, key, value):
         """Tuning knob (see tsta_engine_set_option in include/tsta_engine.h); results never depend on it."""

@@ -159,6 +159,22 @@ void tsta_engine_destroy(tsta_engine* eng)
 
 void tsta_free(void* p) { free(p); }
 
+int tsta_engine_release_workspaces(tsta_engine* eng)
+{
+    if (!eng) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
+    if (rc != TSTA_OK) return rc;
+    if ((rc = e->check(hipStreamSynchronize(e->stream), "hipStreamSynchronize")) != TSTA_OK) return rc;
+    // everything but the small counter block (ticket words, self-test / result scalars)
+    for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
+                            &e->pair_flags, &e->unpacked}) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr; b->bytes = 0;
+    }
+    return TSTA_OK;
+}
+
 int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
 {
     if (!eng || !key) return TSTA_ERR_INVALID_ARG;
