@@ -250,12 +250,13 @@ def test_batch_packed_trace_fill(eng, scoring):
     want = [util.oracle_align(s1, s2, **scoring) for s1, s2 in cases]
     try:
         eng.set_option("trace_rows", 4)
-        for packed in (1, 0):
-            eng.set_option("trace_packed", packed)
+        for packed, elide, perm in ((1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0), (0, 1, 1)):
+            eng.set_option("trace_packed", packed); eng.set_option("psa_elide", elide); eng.set_option("psa_perm", perm)
             for tile in (64, 256):
                 eng.set_option("trace_tile", tile)
                 res = eng.psa_align_batch(cases, tsta_amd.Params(**scoring))
                 for w, got, (s1, s2) in zip(want, res, cases):
-                    assert got == (w[0], w[2], w[3]), (packed, tile, len(s1), len(s2), scoring)
+                    assert got == (w[0], w[2], w[3]), (packed, elide, perm, tile, len(s1), len(s2), scoring)
     finally:
         eng.set_option("trace_rows", 0); eng.set_option("trace_packed", 1); eng.set_option("trace_tile", 0)
+        eng.set_option("psa_elide", 1); eng.set_option("psa_perm", 1)

@@ -417,6 +417,13 @@ template <int R> struct JobGeom {
     size_t total() const { return rows_bytes + state_bytes + trace_bytes + ops_bytes + seq_bytes + 256; }
 };
 
+static bool pure_acgt(const HostJob& J)
+{
+    for (int i = 0; i < J.n; ++i) { const uint8_t c = J.a[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false; }
+    for (int i = 0; i < J.m; ++i) { const uint8_t c = J.b[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false; }
+    return true;
+}
+
 // can the packed 16-bit trace fill (psa_trace_packed.hip) take this scoring?  (same domain as K1p at R = kPackedTraceR)
 static bool packed_trace_fits(const tsta_params& p)
 {
@@ -452,6 +459,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             const int64_t pn = std::max(jobs[x].n, jobs[y].n), pm = std::max(jobs[x].m, jobs[y].m);
             if (5 * pn * pm > 4 * ((int64_t)jobs[x].n * jobs[x].m + (int64_t)jobs[y].n * jobs[y].m)) continue;
             TraceCouple c; c.ja = x; c.jb = y; c.band0 = 0; c.W = 0; c.S_total = 0; c.state = nullptr;
+            c.perm = (e->opt_psa_perm != 0 && pure_acgt(jobs[x]) && pure_acgt(jobs[y])) ? 1 : 0;
             couple_of[x] = couple_of[y] = (int)tc.size();
             lay_n[x] = lay_n[y] = (int)pn; lay_m[x] = lay_m[y] = (int)pm;
             tc.push_back(c);
@@ -539,6 +547,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     {
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         B.pe = ae | (ae << 16); B.po = ao | (ao << 16); B.pm = am | (am << 16); B.pmx = amx | (amx << 16);
+        B.elide = e->opt_psa_elide != 0 &&
+                  psa_packed_window(p->M, p->X, p->E, p->O, kPackedTraceR) + (int64_t)ae * (32 * (kPackedTraceR + 1) + 192) < 28000;
     }
     // The couples are independent of each other: split them into up to 4 chunks with their own band numbering and
     // their own stream, so that the launch sequences overlap (one sequence's launch gaps and half-empty tails are

@@ -50,29 +50,32 @@ __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned k, unsigned c)
 // packed constants of the trace code, pinned in VGPRs
 struct PkConst { unsigned one, mone, k2, k4, k16, k20, k21; };
 
-// One step of the lane's R rows for both jobs (see psa_score_packed.hip: pstep for the recurrence and the masks);
+// One step of the lane's R rows for both jobs WITH the trace codes (the score-only tiles use packed_step.h directly).
 // code[k] = per half, the trace byte of row k: nd + 2nf + 4(fge+1) + 16(ege+1) = (nd + 20) + 2nf + 4fge + 16ege with
 // fge, ege in {-1,0,1}; the +20 rides on nd so that every partial sum stays a non-negative byte.
-template <int R, bool PRED, bool PARTIAL, bool TRACE>
+// ELIDED: the block provably cannot raise either job's maximum (packed_step.h): no running max, and the frame in
+// which the vertical gap costs nothing (pe unused, pf = 2|E|+M); implies !PRED, and needs no PARTIAL masks.
+template <int R, bool PRED, bool PARTIAL, bool PERM, bool ELIDED>
 __device__ __forceinline__ void ptstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
                                        const int nvA, const int nvB, const unsigned pe, const unsigned po, const unsigned pm,
                                        const unsigned pmx, const unsigned pf, const PkConst& K, unsigned (&code)[R])
 {
     unsigned hu, eu;
-    lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
+    if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
+    else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     unsigned d = s.hd;
     unsigned h = 0;
     unsigned m = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const unsigned e = eu - pe;                      // E' = Ebar'(up) - |E|
-        const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)
-        const unsigned tt = pkmin(s.cch ^ s.bch[k], pmx);
+        const unsigned e = ELIDED ? eu : eu - pe;        // E' = Ebar'(up) - |E|    (E* = Ebar*(up))
+        const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)   (F*: 2|E|+M)
+        const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);
         const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
         h = pkmax(pkmax(dg, e), f);
         const unsigned g = h - po;                       // H' + O
-        if (TRACE) {
+        {
             const unsigned nd = pkmin((h + K.k20) - dg, K.k21);   // psa.c:294-299: back; min(x,1) + 20 (x >= 0): bytes stay >= 0
             const unsigned nf = pkmin(h - f, K.one);
             const unsigned fge = pk_sign(g, f, K.mone, K.one);    // psa.c:302-313 (fback), one cell to the left of where it is used
@@ -82,8 +85,6 @@ __device__ __forceinline__ void ptstep(PLane<R>& s, const int t, const int lane,
         const unsigned eb = pkmax(e, g);
         const unsigned fbn = pkmax(f, g);
         d = s.hl[k];
-        unsigned hv = h;
-        if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);
         if (PRED) {
             s.hl[k] = act ? h : s.hl[k];
             s.fb[k] = act ? fbn : s.fb[k];
@@ -91,54 +92,52 @@ __device__ __forceinline__ void ptstep(PLane<R>& s, const int t, const int lane,
             s.hl[k] = h;
             s.fb[k] = fbn;
         }
-        m = (k == 0) ? hv : pkmax(m, hv);
+        if (!ELIDED) {
+            unsigned hv = h;
+            if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);
+            m = (k == 0) ? hv : pkmax(m, hv);
+        }
         eu = eb;
     }
     s.hbot = h;
     s.ebot = eu;
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
-    unsigned cand = m + s.joff;                          // running max in the H frame (see pstep)
-    if (PRED) {
-        const unsigned c = (unsigned)(t - lane);
-        cand &= ((c < (unsigned)nA) ? 0xffffu : 0u) | ((c < (unsigned)nB) ? 0xffff0000u : 0u);
+    if (!ELIDED) {
+        unsigned cand = m + s.joff;                      // running max in the H frame (see pstep)
+        if (PRED) {
+            const unsigned c = (unsigned)(t - lane);
+            cand &= ((c < (unsigned)nA) ? 0xffffu : 0u) | ((c < (unsigned)nB) ? 0xffff0000u : 0u);
+        }
+        if (PARTIAL) cand &= ((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u);
+        s.mx = pkmax(s.mx, cand);
+        s.joff += pm;
     }
-    if (PARTIAL) cand &= ((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u);
-    s.mx = pkmax(s.mx, cand);
-    s.joff += pm;
 }
 
-// 64 steps; the trace bytes of every 16/R steps leave as one uint4 per lane and job
-template <int R, bool PRED, bool PARTIAL, bool TRACE>
+// 64 steps with trace; the trace bytes of every 16/R steps leave as one uint4 per lane and job
+template <int R, bool PRED, bool PARTIAL, bool PERM, bool ELIDED>
 __device__ __forceinline__ void ptblock(PLane<R>& s, const int t0, const int lane, const int n, const int nA, const int nB,
                                         const int nvA, const int nvB, const unsigned pe, const unsigned po, const unsigned pm,
                                         const unsigned pmx, const unsigned pf, const PkConst& K,
                                         uint4* __restrict__ tqA, uint4* __restrict__ tqB)
 {
-    if constexpr (TRACE) {
-        static_assert(R == 4, "byte gather below is written for 4 rows per lane");
-        constexpr int SPB = TraceCfg<R>::SPB;
+    static_assert(R == 4, "byte gather below is written for 4 rows per lane");
+    constexpr int SPB = TraceCfg<R>::SPB;
 #pragma unroll 1
-        for (int g = 0; g < 64 / SPB; ++g) {
-            unsigned accA[4], accB[4];
+    for (int g = 0; g < 64 / SPB; ++g) {
+        unsigned accA[4], accB[4];
 #pragma unroll
-            for (int q = 0; q < SPB; ++q) {
-                unsigned code[R];
-                ptstep<R, PRED, PARTIAL, true>(s, t0 + g * SPB + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
-                // bytes 0 / 2 of the four codes -> one dword per job (v_perm_b32: selectors 0-3 second operand, 4-7 first)
-                const unsigned p01 = __builtin_amdgcn_perm(code[1], code[0], 0x06020400u);   // A0 A1 B0 B1
-                const unsigned p23 = __builtin_amdgcn_perm(code[3], code[2], 0x06020400u);   // A2 A3 B2 B3
-                accA[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-                accB[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
-            }
-            tqA[(size_t)g * 64] = make_uint4(accA[0], accA[1], accA[2], accA[3]);
-            tqB[(size_t)g * 64] = make_uint4(accB[0], accB[1], accB[2], accB[3]);
-        }
-    } else {
-#pragma unroll 2
-        for (int q = 0; q < 64; ++q) {
+        for (int q = 0; q < SPB; ++q) {
             unsigned code[R];
-            ptstep<R, PRED, PARTIAL, false>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
+            ptstep<R, PRED, PARTIAL, PERM, ELIDED>(s, t0 + g * SPB + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, code);
+            // bytes 0 / 2 of the four codes -> one dword per job (v_perm_b32: selectors 0-3 second operand, 4-7 first)
+            const unsigned p01 = __builtin_amdgcn_perm(code[1], code[0], 0x06020400u);   // A0 A1 B0 B1
+            const unsigned p23 = __builtin_amdgcn_perm(code[3], code[2], 0x06020400u);   // A2 A3 B2 B3
+            accA[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+            accB[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
         }
+        tqA[(size_t)g * 64] = make_uint4(accA[0], accA[1], accA[2], accA[3]);
+        tqB[(size_t)g * 64] = make_uint4(accB[0], accB[1], accB[2], accB[3]);
     }
 }
 
@@ -161,7 +160,6 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
                                             const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
                                             const bool elide_ok)
 {
-    static_assert(!(TRACE && PERM), "the trace step has no byte-permute form yet");
     constexpr int SPB = TraceCfg<TRACE ? R : 4>::SPB;
     const int nA = V.nA, mA = V.mA, nB = V.nB, mB = V.mB, w = V.w;
     const int n = max(nA, nB), nmin = min(nA, nB), mmin = min(mA, mB);
@@ -283,36 +281,38 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             tqB = reinterpret_cast<uint4*>(V.tbandB) + ((size_t)(t0 / SPB) * 64 + ln);
         }
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
-        if constexpr (TRACE) {
-            if (steady && !partial)      ptblock<R, false, false, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-            else if (steady)             ptblock<R, false, true, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-            else                         ptblock<R, true, true, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
-        } else {
-            // score only: K1p's steps, including the blocks that provably cannot raise the maximum (packed_step.h)
-            bool elide = false;
-            if (steady && elide_ok)
-                elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, ae, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
-                                : block_cannot_raise_max<R, false>(s, acc, in_star, ln, ae, nvA, nvB, true, true, t0, M);
-            if (elide != in_star) {                    // frame change only where the kind of block changes
-                if (elide) elided_frame<R>(s, ln, ae, +1, 0);
-                else       elided_frame<R>(s, ln, ae, -1, lag);
-                in_star = elide;
-            }
-            if (elide) {
-                { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+        // blocks that provably cannot raise either maximum run without the running max, in the H* frame (packed_step.h)
+        bool elide = false;
+        if (steady && elide_ok)
+            elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, ae, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
+                            : block_cannot_raise_max<R, false>(s, acc, in_star, ln, ae, nvA, nvB, true, true, t0, M);
+        if (elide != in_star) {                        // frame change only where the kind of block changes
+            if (elide) elided_frame<R>(s, ln, ae, +1, 0);
+            else       elided_frame<R>(s, ln, ae, -1, lag);
+            in_star = elide;
+        }
+        if (elide) {
+            { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+            if constexpr (TRACE) {
+                ptblock<R, false, false, PERM, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf2, K, tqA, tqB);
+            } else {
 #pragma unroll 2
                 for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
-                { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
-            } else if (steady && !partial) {
-#pragma unroll 2
-                for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
-            } else if (steady) {
-#pragma unroll 2
-                for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
-            } else {
-#pragma unroll 1
-                for (int q = 0; q < 64; ++q) pstep<R, true, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
             }
+            { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
+        } else if constexpr (TRACE) {
+            if (steady && !partial)      ptblock<R, false, false, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+            else if (steady)             ptblock<R, false, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+            else                         ptblock<R, true, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
+        } else if (steady && !partial) {
+#pragma unroll 2
+            for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+        } else if (steady) {
+#pragma unroll 2
+            for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < 64; ++q) pstep<R, true, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
         const int cs = t0 - 64 + ln;
         if (V.store_bottom && cs >= 0 && cs < n) {
@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
     V.tbandA = JA.trace + (size_t)w * JA.band_bytes; V.tbandB = JB.trace + (size_t)w * JB.band_bytes;
     V.st = C.state + (size_t)w * NS * 64;
     V.w = w;
-    packed_tile<R, true, false>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, false);
+    if (C.perm) packed_tile<R, true, true>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
+    else        packed_tile<R, true, false>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
 }
 
 // per couple (blockIdx.x): out[0] of both jobs = max over all lanes' running maxima, floored at -100 (psa.c:590)

@@ -41,6 +41,7 @@ struct TraceCouple {
     int  ja, jb;                    // indices into the job table
     int  band0;                     // first band among the bands of all couples of the group
     int  W, S_total;                // bands / steps per band of the couple
+    int  perm;                      // 1: all four sequences are pure ACGT: byte-permute mismatch lookup (packed_step.h)
     int* state;                     // [W][packed_state_ints(R)][64] packed per-lane state between tiles
 };
 
@@ -50,6 +51,7 @@ struct PsaTracePackedArgs {
     int T, d;
     int M, X, E, O;
     unsigned pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
+    int elide;                      // 1: blocks that provably cannot raise the maximum drop the running max (packed_step.h)
 };
 
 // ints of per-lane state a packed band keeps between tiles: hl/fb[R], hd, hbot, ebot, cch, mxA, mxB, baseA, baseB, in_star, cch2
