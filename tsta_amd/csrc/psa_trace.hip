@@ -504,13 +504,16 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     const bool persistent = n_singles > 0 && e->opt_trace_persistent != 0;
     int sband0 = 0, cband0 = 0, max_n = 0;
     std::vector<TraceJob> singles;
+    std::vector<uint8_t> h_seq(seq_b);
     for (int j = 0; j < n_jobs; ++j) {
         const JobGeom<R> g(jobs[j].n, jobs[j].m, lay_n[j], lay_m[j], TRACE);
         TraceJob& J = tj[j];
         J.a = reinterpret_cast<const uint8_t*>(d_seq); J.b = J.a + jobs[j].n; J.n = jobs[j].n; J.m = jobs[j].m;
-        if ((rc = e->check(hipMemcpyAsync(d_seq, jobs[j].a, jobs[j].n, hipMemcpyHostToDevice, s), "H2D a")) ||
-            (rc = e->check(hipMemcpyAsync(d_seq + jobs[j].n, jobs[j].b, jobs[j].m, hipMemcpyHostToDevice, s), "H2D b")))
-            return rc;
+        {   // one staging buffer, one H2D for all jobs (thousands of short pairs would otherwise be thousands of copies)
+            const size_t off = (size_t)(d_seq - reinterpret_cast<char*>(e->in_seqs.p));
+            memcpy(h_seq.data() + off, jobs[j].a, (size_t)jobs[j].n);
+            memcpy(h_seq.data() + off + jobs[j].n, jobs[j].b, (size_t)jobs[j].m);
+        }
         J.rows = reinterpret_cast<int2*>(d_rows); J.row_stride = g.row_stride;
         J.trace = reinterpret_cast<uint8_t*>(d_trace); J.band_bytes = g.band_bytes;
         J.W = g.W; J.S_total = g.S_total;
@@ -532,7 +535,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     }
     // couples were numbered in creation order but their bands in job order of their first member: renumber by band0
     std::sort(tc.begin(), tc.end(), [](const TraceCouple& x, const TraceCouple& y) { return x.band0 < y.band0; });
-    if ((rc = e->check(hipMemcpyAsync(d_jobs, tj.data(), tj.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D jobs")) ||
+    if ((rc = e->check(hipMemcpyAsync(e->in_seqs.p, h_seq.data(), seq_b, hipMemcpyHostToDevice, s), "H2D sequences")) ||
+        (rc = e->check(hipMemcpyAsync(d_jobs, tj.data(), tj.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D jobs")) ||
         (n_singles && (rc = e->check(hipMemcpyAsync(d_singles, singles.data(), singles.size() * sizeof(TraceJob), hipMemcpyHostToDevice, s), "H2D singles"))) ||
         (n_couples && (rc = e->check(hipMemcpyAsync(d_couples, tc.data(), tc.size() * sizeof(TraceCouple), hipMemcpyHostToDevice, s), "H2D couples"))))
         return rc;
@@ -640,11 +644,25 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if ((rc = e->check(hipMemcpy(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost), "D2H status"))) return rc;
         if (st) { e->set_error("persistent trace fill: a band waited too long for the band above (status %u)", st); return TSTA_ERR_INTERNAL; }
     }
+    // the walkers' ops: per-job copies for a few long alignments, one copy of the whole region for many short ones
+    std::vector<uint8_t> h_ops;
+    const bool one_copy = TRACE && n_jobs > 16;
+    if (one_copy) {
+        h_ops.resize(ops_b);
+        if ((rc = e->check(hipMemcpyAsync(h_ops.data(), e->scratch2.p, ops_b, hipMemcpyDeviceToHost, s), "D2H ops")) ||
+            (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
+            return rc;
+    }
     for (int j = 0; j < n_jobs; ++j) {
         jobs[j].maxscore = h_out[8 * j]; jobs[j].end_score = h_out[8 * j + 1];
         if (!TRACE) continue;
         const int cnt = h_out[8 * j + 2]; jobs[j].fi = h_out[8 * j + 3]; jobs[j].fj = h_out[8 * j + 4];
         if (cnt < 0 || cnt > jobs[j].n + jobs[j].m) { e->set_error("walker returned %d ops", cnt); return TSTA_ERR_INTERNAL; }
+        if (one_copy) {
+            const uint8_t* src = h_ops.data() + (tj[j].ops - reinterpret_cast<const uint8_t*>(e->scratch2.p));
+            jobs[j].ops.assign(src, src + cnt);
+            continue;
+        }
         jobs[j].ops.resize(cnt);
         if (cnt && (rc = e->check(hipMemcpyAsync(jobs[j].ops.data(), tj[j].ops, cnt, hipMemcpyDeviceToHost, s), "D2H ops"))) return rc;
     }
