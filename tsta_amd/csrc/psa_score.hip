@@ -45,14 +45,13 @@ __device__ __forceinline__ void psa_step(LaneState<R>& s, const int t, const int
                                          const int nvalid, const int M, const int X, const int E, const int O)
 {
     // cross-lane traffic first, on all lanes (DPP must not run under a partial EXEC mask)
-    s.cch = wave_shr1(s.ach, s.cch);
-    const int hu = wave_shr1(s.th, s.hbot);
-    int eu = wave_shr1(s.te, s.ebot);
-    s.sh = wave_shl1(s.hbot, s.sh);
-    s.se = wave_shl1(s.ebot, s.se);
-    s.th = wave_shl1(s.th, s.th);
-    s.te = wave_shl1(s.te, s.te);
-    s.ach = wave_shl1(s.ach, s.ach);
+    // (one asm block of 8 DPP instructions, wave_ops.h: lane_exchange)
+    unsigned hu_u, eu_u;
+    lane_exchange(reinterpret_cast<unsigned&>(s.cch), hu_u, eu_u, reinterpret_cast<unsigned&>(s.sh), reinterpret_cast<unsigned&>(s.se),
+                  reinterpret_cast<unsigned&>(s.ach), reinterpret_cast<unsigned&>(s.th), reinterpret_cast<unsigned&>(s.te),
+                  (unsigned)s.hbot, (unsigned)s.ebot);
+    const int hu = (int)hu_u;
+    int eu = (int)eu_u;
 
     const bool act = !PRED || ((unsigned)(t - lane) < (unsigned)n);
     int d = s.hd;
