@@ -50,6 +50,9 @@ template <int KC>
 __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
 {
     constexpr int kCW = 64 * KC;
+    // rows of this tile as the wave finishes them (KC = 2 only: 33 KB; KC = 4 would not fit the 64 KB of a block)
+    __shared__ int tile_h[KC == 2 ? kRB : 1][KC == 2 ? kCW + 1 : 1];
+    __shared__ int tile_e[KC == 2 ? kRB : 1][KC == 2 ? kCW : 1];
     const int lane = threadIdx.x;
     const int q = A.q_lo + blockIdx.x, rb = A.d - q;
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
@@ -135,8 +138,14 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                 hv[0] = dpp_shr1(edge, hs_prev[KC - 1]);
 #pragma unroll
                 for (int k = 0; k < KC; ++k) { hv[k + 1] = hs_prev[k]; ev[k] = es_prev[k]; }
+            } else if (KC == 2 && p >= r0 && p < r1) {
+                // a row this wave finished earlier in this tile: from the tile's LDS copy (no wait for the stores)
+                const int ip = p - r0;
+                hv[0] = tile_h[ip][lane * KC];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { hv[k + 1] = tile_h[ip][lane * KC + 1 + k]; ev[k] = tile_e[ip][lane * KC + k]; }
             } else {
-                if (p >= r0 && p < r1 && !synced) {          // written by this wave earlier in this tile
+                if (p >= r0 && p < r1 && !synced) {          // written by this wave earlier in this tile (KC = 4: no LDS copy)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -248,6 +257,11 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
             }
         }
         if (q == 0 && lane == 0) Hr[3] = h0;                 // H(r, 0)
+        if constexpr (KC == 2) {                             // the tile's own copy of the row: H(r, cbase .. cbase+kCW), Eagg
+            if (lane == 0) tile_h[i][0] = (q == 0) ? h0 : __builtin_amdgcn_readlane(edge_l, i);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) { tile_h[i][lane * KC + 1 + k] = hs[k]; tile_e[i][lane * KC + k] = es[k]; }
+        }
 #pragma unroll
         for (int k = 0; k < KC; ++k) { hs_prev[k] = hs[k]; es_prev[k] = es[k]; }
         prev_r = r; h0_prev = h0;
