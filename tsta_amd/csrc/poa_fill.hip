@@ -307,6 +307,7 @@ struct PoaWalkArgs {
 __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 {
     __shared__ uint4 win[3][64][4];      // [array][row][64 bytes]
+    __shared__ int wpo[64], wnp[64], wpred[64][4];   // predecessor lists of the window's rows (first 4 of each)
     const int lane = threadIdx.x;
     // start: best sink among sort indices >= 1 (max lastsorce, lowest index on ties), else the last node (:737-750)
     int bv = INT_MIN, bi = -1;
@@ -342,6 +343,16 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) win[a][lane][x] = t[a][x];
+            // the rows' predecessor lists: two dependent global loads per walk step otherwise
+            int po = 0, np_ = 0, pr[4] = {-1, -1, -1, -1};
+            if (rr < A.V) {
+                po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (x < np_) pr[x] = A.pred[po + x];
+            }
+            wpo[lane] = po; wnp[lane] = np_;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) wpred[lane][x] = pr[x];
         }
         __syncthreads();
         const int8_t* wb = reinterpret_cast<const int8_t*>(win);
@@ -356,11 +367,48 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
             if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + (A.skew ? 49 : 64)) break;   // restage
+            if (forced < 0) {
+                // ---- run of match / mismatch cells along the backbone, taken at once: lane l probes cell
+                // (num1 - l, num2 - l); the run continues while the cell is a diagonal move (:786-860, :861-956) whose
+                // predecessor is the row just above, all inside the window
+                const int r = num1 - lane, c = num2 - lane;
+                bool have = false, okc = false;
+                int code_l = 0;
+                if (r >= rw0 && c >= 0) {
+                    const int sk = A.skew ? (r & 63) : 0;
+                    const int off = c + sk - ((cw0 + sk) & ~15);
+                    if (off >= 0 && off < 64) {
+                        have = true;
+                        code_l = wb[(0 * 64 + (r - rw0)) * 64 + off];
+                        const int kind_l = code_l / 42, pidx_l = code_l % 42;
+                        okc = (kind_l == 1 || kind_l == 2) && pidx_l < 4 && pidx_l < wnp[r - rw0] && r >= 1 &&
+                              wpred[r - rw0][pidx_l] == r - 1;
+                    }
+                }
+                const unsigned long long mask = __ballot(okc);
+                const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
+                if (run > 0) {
+                    const int nxt_code = __shfl_down(code_l, 1, 64);
+                    const int nxt_have = __shfl_down(have ? 1 : 0, 1, 64);
+                    if (lane < run) {
+                        int pk = 0;
+                        if (c - 1 >= 0) {
+                            const int cc = (lane < 63 && nxt_have) ? nxt_code : rd(0, r - 1, c - 1);
+                            pk = (cc / 42 == 1);
+                        }
+                        tsta_poa_step st; st.node = r; st.col = c; st.code = (int8_t)code_l; st.peek = (int8_t)pk; st.pad = 0;
+                        A.steps[ns + lane] = st;
+                    }
+                    ns += run; num1 -= run; num2 -= run;
+                    continue;
+                }
+            }
             int code;
             if (forced >= 0) { code = forced; forced = -1; } else code = __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
             const int kind = code / 42, pidx = code % 42;
-            const int p0 = A.pred_off[num1], np = A.pred_off[num1 + 1] - p0;
-            const int Psub = (pidx < np) ? A.pred[p0 + pidx] : -1;
+            const int wi = num1 - rw0;                          // in the window (checked above)
+            const int np = wnp[wi];
+            const int Psub = (pidx < np) ? (pidx < 4 ? wpred[wi][pidx] : A.pred[wpo[wi] + pidx]) : -1;
             int peek = 0;
             int n1 = num1, n2 = num2;
             if (kind == 3) {                                   // F (:753-772)
