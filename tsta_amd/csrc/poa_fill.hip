@@ -328,6 +328,9 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         {
             const int rr = rw0 + lane;
             uint4 t[3][4];
+            // (the offsets of the rows' predecessor lists travel with the window loads: one round trip less)
+            int po = 0, np_ = 0;
+            if (rr < A.V) { po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po; }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
@@ -339,17 +342,16 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                                                             : make_uint4(0, 0, 0, 0);
                 }
             }
+            // the rows' predecessor lists: two dependent global loads per walk step otherwise
+            int pr[4] = {-1, -1, -1, -1};
+            if (rr < A.V) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (x < np_) pr[x] = A.pred[po + x];
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) win[a][lane][x] = t[a][x];
-            // the rows' predecessor lists: two dependent global loads per walk step otherwise
-            int po = 0, np_ = 0, pr[4] = {-1, -1, -1, -1};
-            if (rr < A.V) {
-                po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (x < np_) pr[x] = A.pred[po + x];
-            }
             wpo[lane] = po; wnp[lane] = np_;
 #pragma unroll
             for (int x = 0; x < 4; ++x) wpred[lane][x] = pr[x];
