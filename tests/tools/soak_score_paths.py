@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""One-off soak (not part of the test suite): larger pairs x random scoring sets, every score path against the int32
+kernel: packed R=32/16/8 with and without elision / byte-permute lookup, band pipeline R=8/16."""
+import sys, time
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
+import numpy as np
+import tsta_amd
+from tests import util
+
+eng = tsta_amd.Engine(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+t0 = time.time()
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+    M = int(rng.integers(0, 7)); X = int(rng.integers(-9, min(M, 1))); E = int(rng.integers(-5, 1)); O = int(rng.integers(-12, 1))
+    prm = tsta_amd.Params(M, X, E, O)
+    pairs = []
+    for k in range(24):
+        n = int(rng.integers(6000, 26000)); m = int(rng.integers(6000, 26000))
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = k % 6
+        if kind == 0: b = util.mutate(a, int(rng.integers(1 << 30)), 0.02 + 0.2 * rng.random())[:m]
+        elif kind == 1: b = util.random_dna(int(rng.integers(1 << 30)), m)
+        elif kind == 2: b = util.low_complexity(int(rng.integers(1 << 30)), m, int(rng.integers(1, 4)))
+        elif kind == 3: b = np.concatenate([a[: n // 3], a[2 * n // 3:]])
+        elif kind == 4: b = np.concatenate([util.random_dna(5, m // 2), a[n // 2:]])[:m]
+        else: b = a[::-1].copy()[:m]
+        if len(b) == 0: b = a[:1]
+        pairs.append((a, b))
+    eng.set_option("psa_packed", 0); eng.set_option("psa_bands", 0)
+    ref = eng.psa_score_batch(pairs, prm)
+    for packed, bands, elide, perm in [(32, -1, 1, 1), (32, -1, 0, 0), (16, -1, 1, 1), (8, -1, 1, 0), (-1, 8, 1, 1), (-1, 16, 1, 1), (-1, 16, 0, 0), (-1, -1, 1, 1)]:
+        eng.set_option("psa_packed", packed); eng.set_option("psa_bands", bands); eng.set_option("psa_elide", elide); eng.set_option("psa_perm", perm)
+        got = eng.psa_score_batch(pairs, prm)
+        if not np.array_equal(got, ref):
+            bad += 1
+            print("MISMATCH", trial, (M, X, E, O), (packed, bands, elide, perm), np.nonzero(got != ref)[0].tolist(), flush=True)
+    print("trial", trial, (M, X, E, O), "ok" if not bad else "BAD", "%.0f s" % (time.time() - t0), flush=True)
+print("mismatches:", bad)
