@@ -423,3 +423,41 @@ def test_2bit_packed_input(eng):
     assert np.array_equal(eng.psa_score_batch_2bit(big), eng.psa_score_batch(big))
     with pytest.raises(tsta_amd.TstaError):
         eng.psa_score_batch_2bit([(np.frombuffer(b"ACGN", dtype=np.uint8), util.random_dna(1, 4))])
+
+
+def test_unequal_couples_garbage_stays_in_range(eng):
+    # Regression (found by tests/tools/soak_score_paths.py): in a couple whose LOW half has fewer columns, that half is
+    # garbage beyond its end; if the garbage leaves the 16-bit window, the 32-bit adds of the packed step carry into
+    # the other pair's half (here: +1 on pair 8 with free gaps, M=4 X=-7 E=0 O=0).  Every packed path vs the int32
+    # kernel on the batch that exposed it, and the affected pair against the oracle.
+    rng = np.random.default_rng(12)
+    M = int(rng.integers(0, 7)); X = int(rng.integers(-9, min(M, 1))); E = int(rng.integers(-5, 1)); O = int(rng.integers(-12, 1))
+    assert (M, X, E, O) == (4, -7, 0, 0)
+    prm = tsta_amd.Params(M, X, E, O)
+    pairs = []
+    for k in range(24):
+        n = int(rng.integers(6000, 26000)); m = int(rng.integers(6000, 26000))
+        a = util.random_dna(int(rng.integers(1 << 30)), n)
+        kind = k % 6
+        if kind == 0: b = util.mutate(a, int(rng.integers(1 << 30)), 0.02 + 0.2 * rng.random())[:m]
+        elif kind == 1: b = util.random_dna(int(rng.integers(1 << 30)), m)
+        elif kind == 2: b = util.low_complexity(int(rng.integers(1 << 30)), m, int(rng.integers(1, 4)))
+        elif kind == 3: b = np.concatenate([a[: n // 3], a[2 * n // 3:]])
+        elif kind == 4: b = np.concatenate([util.random_dna(5, m // 2), a[n // 2:]])[:m]
+        else: b = a[::-1].copy()[:m]
+        pairs.append((a, b))
+    try:
+        eng.set_option("psa_packed", 0); eng.set_option("psa_bands", 0)
+        ref = eng.psa_score_batch(pairs, prm)
+        assert ref[8] == util.oracle_maxscore(pairs[8][0], pairs[8][1], M=M, X=X, E=E, O=O)
+        for packed, bands in ((-1, 16), (-1, 8), (32, -1), (16, -1), (8, -1), (-1, -1)):
+            eng.set_option("psa_packed", packed); eng.set_option("psa_bands", bands)
+            assert np.array_equal(eng.psa_score_batch(pairs, prm), ref), (packed, bands)
+        # the same couples with traceback (K2p shares the packed tile)
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("trace_rows", 4)
+        sub = [pairs[23], pairs[8], pairs[18], pairs[16]]
+        res = eng.psa_align_batch(sub, prm)
+        eng.set_option("trace_packed", 0)
+        assert res == eng.psa_align_batch(sub, prm)
+    finally:
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("trace_rows", 0); eng.set_option("trace_packed", 1)

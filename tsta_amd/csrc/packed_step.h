@@ -149,6 +149,33 @@ __device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx(s.
 
 
 
+// The two pairs of a couple may have different numbers of columns.  Beyond the end of the shorter one its half of every
+// register is garbage that nobody reads — but the plain 32-bit adds / subs of the packed step are only carry-free
+// while BOTH halves stay inside the 16-bit window, so the garbage must stay bounded too.  (1) top-row entries of columns
+// beyond a pair's end enter at the bias level; (2) once no lane of the wave is on a real column of that pair any more
+// (t0 - 63 >= its n) its half of the lane state is flattened to the bias at the start of every block, so it can drift
+// by at most 64 columns' worth of score.
+template <int R>
+__device__ __forceinline__ void flatten_half(PLane<R>& s, const bool low)
+{
+    const unsigned keep = low ? 0xffff0000u : 0x0000ffffu, fill = low ? (unsigned)kBias : ((unsigned)kBias << 16);
+#pragma unroll
+    for (int k = 0; k < R; ++k) { s.hl[k] = (s.hl[k] & keep) | fill; s.fb[k] = (s.fb[k] & keep) | fill; }
+    // (hbot / ebot are left alone: lane 63's still hold the pair's LAST real column on their way into the bottom row;
+    //  from the next step on they are recomputed from the flattened state)
+    s.hd = (s.hd & keep) | fill;
+    s.th = (s.th & keep) | fill; s.te = (s.te & keep) | fill;
+}
+template <int R>
+__device__ __forceinline__ void bound_garbage_columns(PLane<R>& s, const int t0, const int ln, const int nA, const int nB)
+{
+    const int c = t0 + ln;                              // column of this lane's top-row entry
+    if (c >= nA) { s.th = (s.th & 0xffff0000u) | (unsigned)kBias; s.te = (s.te & 0xffff0000u) | (unsigned)kBias; }
+    if (c >= nB) { s.th = (s.th & 0x0000ffffu) | ((unsigned)kBias << 16); s.te = (s.te & 0x0000ffffu) | ((unsigned)kBias << 16); }
+    if (t0 - 63 >= nA) flatten_half<R>(s, true);
+    if (t0 - 63 >= nB) flatten_half<R>(s, false);
+}
+
 // Can the 64-step block starting at t0 raise either pair's maximum?  (see pstep_elided)  Entering H' values: the lanes'
 // previous-column rows, the diagonal entries and the 64 top-row entries; rows beyond the end of a pair hold garbage
 // that no real cell ever reads and do not count.  `in_star`: the lane state is currently in the H* frame.

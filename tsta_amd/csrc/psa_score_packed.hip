@@ -127,6 +127,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
 #pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
+            if (nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);   // beyond the shorter pair's end: keep its half in range
 #pragma unroll 1
             for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }

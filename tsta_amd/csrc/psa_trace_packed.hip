@@ -301,6 +301,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             }
             { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if constexpr (TRACE) {
+            if (!steady && nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);   // beyond the shorter job's end: keep its half in range
             if (steady && !partial)      ptblock<R, false, false, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
             else if (steady)             ptblock<R, false, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
             else                         ptblock<R, true, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
@@ -311,6 +312,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
 #pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         } else {
+            if (nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);
 #pragma unroll 1
             for (int q = 0; q < 64; ++q) pstep<R, true, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
