@@ -12,7 +12,10 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 t0 = time.time()
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
-    M = int(rng.integers(0, 7)); X = int(rng.integers(-9, min(M, 1))); E = int(rng.integers(-5, 1)); O = int(rng.integers(-12, 1))
+    if len(sys.argv) > 3 and sys.argv[3] == 'wide':      # scoring sets that push some paths out of the 16-bit domain
+        M = int(rng.integers(0, 41)); X = int(rng.integers(-60, min(M, 1))); E = int(rng.integers(-20, 1)); O = int(rng.integers(-40, 1))
+    else:
+        M = int(rng.integers(0, 7)); X = int(rng.integers(-9, min(M, 1))); E = int(rng.integers(-5, 1)); O = int(rng.integers(-12, 1))
     prm = tsta_amd.Params(M, X, E, O)
     pairs = []
     for k in range(24):
