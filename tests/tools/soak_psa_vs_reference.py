@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One-off soak on the GPU box (not part of the test suite): random pairs through the drop-in TSTA_psa (GPU) and the
+compiled reference (oracle/_ref/TSTA_psa), byte comparison of stdout and the output files."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tests import util
+ref = os.path.join(util.REF_DIR, "TSTA_psa")
+assert os.path.exists(ref), "needs oracle/_ref/TSTA_psa"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+def fasta(path, name, seq):
+    with open(path, "wb") as f:
+        f.write(b">" + name + b"\n" + bytes(seq) + b"\n")
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
+    n = int(rng.integers(200, 20000)); m = int(rng.integers(200, 20000))
+    a = util.random_dna(int(rng.integers(1 << 30)), n)
+    kind = trial % 4
+    if kind == 0: b = util.mutate(a, int(rng.integers(1 << 30)), 0.02 + 0.2 * rng.random())[:m]
+    elif kind == 1: b = util.random_dna(int(rng.integers(1 << 30)), m)
+    elif kind == 2: b = util.low_complexity(int(rng.integers(1 << 30)), m, 2)
+    else: b = np.concatenate([a[: n // 3], a[2 * n // 3:]])
+    sc = [(2, -5, -2, -4), (1, -1, -1, 0), (3, -4, -3, -4), (2, -3, -2, -4), (5, -4, -1, -10)][int(rng.integers(0, 5))]
+    fasta("/tmp/sa.fa", b"a", a); fasta("/tmp/sb.fa", b"b", b)
+    args = ["-M", str(sc[0]), "-X", str(sc[1]), "-E", str(sc[2]), "-O", str(sc[3]), "-1", "/tmp/sa.fa", "-2", "/tmp/sb.fa"]
+    x = subprocess.run([os.path.join(ROOT, "tsta_amd/bin/TSTA_psa")] + args + ["-o", "/tmp/ours.txt"], capture_output=True)
+    y = subprocess.run([ref, "-T", "16"] + args + ["-o", "/tmp/ref.txt"], capture_output=True)
+    same = x.returncode == 0 and y.returncode == 0 and x.stdout == y.stdout and open("/tmp/ours.txt", "rb").read() == open("/tmp/ref.txt", "rb").read()
+    bad += 0 if same else 1
+    print("trial", trial, (n, len(b), sc), "MATCH" if same else "DIFFER", x.stdout[:30], y.stdout[:30], flush=True)
+print("mismatches:", bad)
