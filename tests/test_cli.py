@@ -106,3 +106,12 @@ def test_batch_cli(built, tmp_path):
         ms, end, ra, rb = util.oracle_align(a, b)
         expect += b">1\n" + ra + b"\n>2\n" + rb + b"\n"
     assert out.read_bytes() == expect
+    # with -A: all pairs (every record of -1 against every record of -2), sequences stored once
+    fa3, fb3 = tmp_path / "a3.fa", tmp_path / "b3.fa"
+    fa3.write_bytes(b"".join(b">a%d\n" % i + bytes(p[0]) + b"\n" for i, p in enumerate(pairs[:5])))
+    fb3.write_bytes(b"".join(b">b%d\n" % i + bytes(p[1]) + b"\n" for i, p in enumerate(pairs[:7])))
+    r = run([os.path.join(built, "TSTA_psa_batch"), "-1", str(fa3), "-2", str(fb3), "-A"])
+    assert r.returncode == 0, r.stderr
+    cross = [(pairs[i][0], pairs[j][1]) for i in range(5) for j in range(7)]
+    wc = util.oracle_maxscore_batch(cross)
+    assert r.stdout == b"".join(b"%d\t%d\tmaxsorce=%d\n" % (k // 7 + 1, k % 7 + 1, w) for k, w in enumerate(wc))

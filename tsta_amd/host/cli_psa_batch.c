@@ -5,7 +5,9 @@
  * With -o <file>: every pair is aligned WITH traceback (tsta_psa_align_batch, the pairs' fills in flight together)
  * and <file> receives, per pair, exactly the bytes TSTA_psa writes to its output file (">1\n" row ">\n>2\n" row,
  * psa.c:512-516) followed by one "\n" as record separator.
- *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O] [-o alignments.txt]        env TSTA_DEVICE = GPU index */
+ * With -A: ALL pairs — every record of -1 against every record of -2 (row-major: -2 varies fastest); each sequence is
+ * stored once on the device, the pairs only carry offsets.  Lines then read "<i>\t<j>\tmaxsorce=%d" (1-based records).
+ *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O] [-A] [-o alignments.txt]        env TSTA_DEVICE = GPU index */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,8 +20,9 @@ int main(int argc, char* argv[])
 {
     tsta_params prm = {2, -5, -2, -4};
     const char *input1 = NULL, *input2 = NULL, *output = NULL;
+    int all_pairs = 0;
     int c;
-    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:o:")) != -1) {
+    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:o:A")) != -1) {
         switch (c) {
             case 'M': prm.M = atoi(optarg); break;
             case 'X': prm.X = atoi(optarg); break;
@@ -29,24 +32,33 @@ int main(int argc, char* argv[])
             case '1': input1 = optarg; break;
             case '2': input2 = optarg; break;
             case 'o': output = optarg; break;
-            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-o alignments.txt]\n"); return 2;
+            case 'A': all_pairs = 1; break;
+            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-o alignments.txt]\n"); return 2;
         }
     }
-    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-o alignments.txt]\n"); return 2; }
+    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-o alignments.txt]\n"); return 2; }
     fasta_file* f1 = fasta_read(input1, 0);
     fasta_file* f2 = fasta_read(input2, 0);
-    if (f1->count != f2->count) { fprintf(stderr, "record counts differ: %zu vs %zu\n", f1->count, f2->count); return 1; }
-    const size_t n = f1->count;
+    if (!all_pairs && f1->count != f2->count) { fprintf(stderr, "record counts differ: %zu vs %zu (use -A for all pairs)\n", f1->count, f2->count); return 1; }
+    const size_t n1 = f1->count, n2 = f2->count;
+    const size_t n = all_pairs ? n1 * n2 : n1;
+    if (n > ((size_t)1 << 24)) { fprintf(stderr, "too many pairs: %zu\n", n); return 1; }
+    /* every sequence once: all -1 records, then all -2 records */
     size_t total = 0;
-    for (size_t k = 0; k < n; k++) total += f1->seqs[k].length + f2->seqs[k].length;
+    for (size_t k = 0; k < n1; k++) total += f1->seqs[k].length;
+    for (size_t k = 0; k < n2; k++) total += f2->seqs[k].length;
     uint8_t* seqs = (uint8_t*)malloc(total ? total : 1);
+    int64_t* start1 = (int64_t*)malloc((n1 ? n1 : 1) * sizeof(int64_t)); int64_t* start2 = (int64_t*)malloc((n2 ? n2 : 1) * sizeof(int64_t));
+    size_t pos = 0;
+    for (size_t k = 0; k < n1; k++) { start1[k] = (int64_t)pos; memcpy(seqs + pos, f1->seqs[k].data, f1->seqs[k].length); pos += f1->seqs[k].length; }
+    for (size_t k = 0; k < n2; k++) { start2[k] = (int64_t)pos; memcpy(seqs + pos, f2->seqs[k].data, f2->seqs[k].length); pos += f2->seqs[k].length; }
     int64_t* off1 = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t)); int64_t* off2 = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t));
     int32_t* len1 = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t)); int32_t* len2 = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
     int32_t* out = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
-    size_t pos = 0;
     for (size_t k = 0; k < n; k++) {
-        off1[k] = (int64_t)pos; len1[k] = (int32_t)f1->seqs[k].length; memcpy(seqs + pos, f1->seqs[k].data, f1->seqs[k].length); pos += f1->seqs[k].length;
-        off2[k] = (int64_t)pos; len2[k] = (int32_t)f2->seqs[k].length; memcpy(seqs + pos, f2->seqs[k].data, f2->seqs[k].length); pos += f2->seqs[k].length;
+        const size_t i = all_pairs ? k / n2 : k, j = all_pairs ? k % n2 : k;
+        off1[k] = start1[i]; len1[k] = (int32_t)f1->seqs[i].length;
+        off2[k] = start2[j]; len2[k] = (int32_t)f2->seqs[j].length;
     }
     const char* dev = getenv("TSTA_DEVICE");
     tsta_engine* eng = NULL;
@@ -71,9 +83,12 @@ int main(int argc, char* argv[])
         rc = tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
         if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
     }
-    for (size_t k = 0; k < n; k++) printf("maxsorce=%d\n", out[k]);
+    for (size_t k = 0; k < n; k++) {
+        if (all_pairs) printf("%zu\t%zu\tmaxsorce=%d\n", k / n2 + 1, k % n2 + 1, out[k]);
+        else           printf("maxsorce=%d\n", out[k]);
+    }
     tsta_engine_destroy(eng);
     fasta_free(f1); fasta_free(f2);
-    free(seqs); free(off1); free(off2); free(len1); free(len2); free(out);
+    free(seqs); free(off1); free(off2); free(len1); free(len2); free(out); free(start1); free(start2);
     return 0;
 }
