@@ -13,10 +13,10 @@ out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def stats(sub, name):
-    f = glob.glob(os.path.join(base, sub, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(base, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if not f:
         return
-    rows = list(csv.DictReader(open(f[0])))
+    rows = list(csv.DictReader(open(f[-1])))          # the newest run (gpurun merges results of earlier calls into the same directory)
     with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as g:
         w = csv.writer(g)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
@@ -27,9 +27,9 @@ def stats(sub, name):
 
 
 def pmc(sub, counter, kernel):
-    f = glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     res = []
-    for r in csv.DictReader(open(f[0])) if f else []:
+    for r in csv.DictReader(open(f[-1])) if f else []:
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             res.append(dict(counter=counter, value_kb=float(r["Counter_Value"]), grid=int(r["Grid_Size"]),
                             wg=int(r["Workgroup_Size"]), vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
