@@ -18,7 +18,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     prm = tsta_amd.Params(M, X, E, O)
     pairs = []
     for k in range(30):
-        n = int(rng.integers(1500, 9000)); m = int(rng.integers(1500, 9000))
+        lo, hi = (1, 400) if os.environ.get("SOAK_SMALL") else (1500, 9000)
+        n = int(rng.integers(lo, hi)); m = int(rng.integers(lo, hi))
         a = util.random_dna(int(rng.integers(1 << 30)), n)
         kind = k % 6
         if kind == 0: b = util.mutate(a, int(rng.integers(1 << 30)), 0.02 + 0.2 * rng.random())[:m]
