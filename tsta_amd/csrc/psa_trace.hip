@@ -59,7 +59,7 @@ struct TLane {
 // bracket is built with three v_lshl_add_u32 (it may be negative), shifted into its byte with a fourth, and the +20
 // of all four bytes of a dword is added once (0x14141414) by the caller — integer arithmetic is linear, borrows
 // between bytes cancel.
-template <int R, bool PRED, bool TRACE>
+template <int R, bool PRED, bool TRACE, bool FULL = false>   // FULL: every row of the band is a real row (no mask on the running max)
 __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int lane, const int n, const int nvalid,
                                            const int M, const int X, const int E, const int O, int (&tb)[(R + 3) / 4])
 {
@@ -91,7 +91,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
         const int eb = max(e, g);
         const int fbn = max(f, g);
         d = s.hl[k];
-        int hv = (k < nvalid) ? h : kNegInfT;
+        int hv = (FULL || k < nvalid) ? h : kNegInfT;
         if (PRED) {
             s.hl[k] = act ? h : s.hl[k];
             s.fb[k] = act ? fbn : s.fb[k];
@@ -108,7 +108,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
 }
 
-template <int R, bool PRED, bool TRACE, bool WT = false>
+template <int R, bool PRED, bool TRACE, bool WT = false, bool FULL = false>
 __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                             const int M, const int X, const int E, const int O, uint4* __restrict__ tq)
 {
@@ -122,7 +122,7 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
             int tb[(R + 3) / 4];
 #pragma unroll
             for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
-            trace_step<R, PRED, TRACE>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
+            trace_step<R, PRED, TRACE, FULL>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
             if constexpr (!TRACE) { (void)acc; }
             else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
@@ -226,8 +226,10 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         if (c < n) { nt = top[c]; na = seq_a[c]; }
         s.th = nt.x; s.te = nt.y; s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
-        if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
-        else                         trace_block<R, true, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        const bool steady = t0 >= 64 && t0 + 63 < n;
+        if (steady && (w + 1) * 64 * R <= m) trace_block<R, false, TRACE, PERSIST, true>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else if (steady)                     trace_block<R, false, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else                                 trace_block<R, true, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
         const int cs = t0 - 64 + lane;
         if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
         if (PERSIST) {
