@@ -19,7 +19,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     prm = tsta_amd.Params(M, X, E, O)
     pairs = []
     for k in range(24):
-        lo, hi = (1, 700) if __import__("os").environ.get("SOAK_SMALL") else (6000, 26000)
+        lo, hi = (1, 700) if __import__("os").environ.get("SOAK_SMALL") else ((30000, 50000) if __import__("os").environ.get("SOAK_BIG") else (6000, 26000))
         n = int(rng.integers(lo, hi)); m = int(rng.integers(lo, hi))
         a = util.random_dna(int(rng.integers(1 << 30)), n)
         kind = k % 6
