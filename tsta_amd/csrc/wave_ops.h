@@ -29,8 +29,10 @@ __device__ __forceinline__ int wave_shl1(int old, int src) {
 //   ach, th, te rotate left by one lane (next column's character / top-row entry into lane 0)
 // `v_cndmask_b32_dpp d, shifted, inject, vcc ... bound_ctrl:0` selects the injected value in the ONE lane named by VCC
 // and the DPP-shifted value elsewhere, so no register copy for an `old` operand and none of the s_nop pairs the
-// compiler puts between such a copy and its v_mov_dpp.  Hazards inside the block: every DPP source was written at least
-// two instructions earlier (hbot/ebot by the caller's last step, then >= 3 instructions of this block come first).
+// compiler puts between such a copy and its v_mov_dpp.  Hazards: a DPP source needs 2 wait states after a VALU write, and
+// the compiler's hazard recognizer does not look into the block, so the block itself guarantees them for anything the
+// caller may have written in its last instruction: s_mov + s_nop come before the first DPP read (cch), every other
+// DPP source is read at least two instructions into the block.
 __device__ __forceinline__ void lane_exchange(unsigned& cch, unsigned& hu, unsigned& eu, unsigned& sh, unsigned& se,
                                               unsigned& ach, unsigned& th, unsigned& te, unsigned hbot, unsigned ebot)
 {
@@ -39,6 +41,7 @@ __device__ __forceinline__ void lane_exchange(unsigned& cch, unsigned& hu, unsig
     eu = ebot;
     asm volatile(
         "s_mov_b64 vcc, 1\n\t"
+        "s_nop 0\n\t"      /* 2 wait states between a VALU write of cch just before the block and its DPP read */
         "v_cndmask_b32_dpp %0, %0, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_lshl_b64 vcc, 1, 63\n\t"
@@ -62,6 +65,7 @@ __device__ __forceinline__ void lane_exchange2(unsigned& cch, unsigned& cch2, un
     eu = ebot;
     asm volatile(
         "s_mov_b64 vcc, 1\n\t"
+        "s_nop 0\n\t"      /* 2 wait states between a VALU write of cch just before the block and its DPP read */
         "v_cndmask_b32_dpp %0, %0, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_cndmask_b32_dpp %8, %8, %9, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
