@@ -79,6 +79,32 @@ def config5h(eng, P=8192, L=50_000):
             "gcups_kernel": P * float(L) * L / k / 1e6, "h2d_bytes": int(h_seqs.size)}
 
 
+def config5s(eng, P=4096, L=50_000):
+    """Not a BASELINE config: the config #5 pair shape with a scoring whose mismatch costs at most two gap extensions
+    (M=2 X=-4 E=-2 O=-4, minimap2's): pure-ACGT couples then run their elided blocks with BOTH gap extensions free."""
+    dev = torch.device("cuda", 0)
+    seqs, off1, len1, off2, len2 = make_shard(P, L, 79, dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    prm = tsta_amd.Params(2, -4, -2, -4)
+    out = {}
+    with torch.cuda.stream(st):
+        for ff in (1, 0):
+            eng.set_option("psa_ffree", ff)
+            ms = []
+            for i in range(2):
+                eng.psa_score_batch_dev(prm, P, seqs.data_ptr(), off1.data_ptr(), len1.data_ptr(), off2.data_ptr(),
+                                        len2.data_ptr(), scores.data_ptr(), L, st.cuda_stream)
+                k, _ = eng.last_kernel_ms()
+                ms.append(k)
+            out[ff] = (ms[-1], scores.clone())
+    eng.set_option("psa_ffree", 1)
+    assert torch.equal(out[0][1], out[1][1])
+    return {"config": "#5 shape, %d pairs of %d x %d, score only, scoring M=2 X=-4 E=-2 O=-4" % (P, L, L),
+            "kernel_ms_free_free_frame": out[1][0], "gcups_free_free_frame": P * float(L) * L / out[1][0] / 1e6,
+            "kernel_ms_without": out[0][0], "gcups_without": P * float(L) * L / out[0][0] / 1e6}
+
+
 def config3(eng):
     x = util.random_dna(777, 100_000); y = util.mutate(x, 778, 0.05)
     eng.psa_align(x[:3000], y[:3000])                       # warm-up (allocations are per-size, this only pages code in)
@@ -157,6 +183,8 @@ if __name__ == "__main__":
         print(json.dumps(config2(eng)), flush=True)
     if "3" in which:
         print(json.dumps(config3(eng)), flush=True)
+    if "5s" in which:
+        print(json.dumps(config5s(eng)), flush=True)
     if "5h" in which:
         print(json.dumps(config5h(eng)), flush=True)
     if "5m" in which:

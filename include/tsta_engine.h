@@ -56,6 +56,7 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      with that many rows per lane; auto uses it for batches too small to fill the chip with K1p
  *   "psa_elide"        1 (default) | 0: packed kernel keeps the running max in every block, also where a bound shows
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
+ *   "psa_ffree"        1 (default) | 0: never use the frame with both gap extensions free (scorings with X >= -2|E|)
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_packed"     1 (default) | 0: tsta_psa_align_batch never couples two pairs per wave (packed 16-bit trace fill)

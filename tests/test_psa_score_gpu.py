@@ -166,16 +166,19 @@ def test_packed_max_elision(eng, scoring):
     want = util.oracle_maxscore_batch(pairs, **scoring)
     try:
         for mode in (32, 16, 8):
-            for elide, perm in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            # (ffree: scorings with X >= -2|E| run the elided blocks of pure-ACGT couples with both gap extensions free)
+            for elide, perm, ffree in ((1, 1, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (0, 0, 0)):
                 eng.set_option("psa_packed", mode)
                 eng.set_option("psa_elide", elide)
                 eng.set_option("psa_perm", perm)
+                eng.set_option("psa_ffree", ffree)
                 got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
-                assert np.array_equal(got, want), (mode, elide, perm, scoring, got.tolist(), want.tolist())
+                assert np.array_equal(got, want), (mode, elide, perm, ffree, scoring, got.tolist(), want.tolist())
     finally:
         eng.set_option("psa_packed", -1)
         eng.set_option("psa_elide", 1)
         eng.set_option("psa_perm", 1)
+        eng.set_option("psa_ffree", 1)
 
 
 def test_packed_adversarial_content(eng):

@@ -24,7 +24,7 @@ struct Engine {
     char        err[512] = {0};
 
     // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
-    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 0, opt_poa_skewed = 0;
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 0, opt_poa_skewed = 0, opt_psa_ffree = 1;
 
     DevBuf counter;      // ticket counters / flags (zeroed per launch)
     DevBuf rows;         // PSA per-wave boundary rows

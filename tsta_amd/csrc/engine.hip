@@ -188,6 +188,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "trace_streams") && (v == 0 || v == 1)) { e->opt_trace_streams = v; return TSTA_OK; }
     if (!strcmp(key, "trace_packed") && (v == 0 || v == 1)) { e->opt_trace_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_bands") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_bands = (int)v; return TSTA_OK; }
+    if (!strcmp(key, "psa_ffree") && (v == 0 || v == 1)) { e->opt_psa_ffree = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "poa_skewed") && (v == 0 || v == 1)) { e->opt_poa_skewed = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }

@@ -49,11 +49,22 @@ inline int64_t psa_packed_window(int64_t M, int64_t X, int64_t E, int64_t O, int
     return (64LL * R + 256) * U - 2LL * O - E + 200LL * M;
 }
 
+// may pure-ACGT couples run their elided blocks in the free-free frame (packed_step.h: pstep_elided<FF>)?  Needs
+// X >= -2|E| (the mismatch addend 2|E|+X is a non-negative byte), 2|E|+M <= 255 and room in the 16-bit window.
+inline bool psa_ffree_ok(int64_t M, int64_t X, int64_t E, int64_t O, int R)
+{
+    const int64_t ae = -E;
+    if (2 * ae + X < 0 || 2 * ae + M > 255) return false;
+    const int64_t col = ae + M, lc = ae * R - col;
+    return psa_packed_window(M, X, E, O, R) + 32 * (lc < 0 ? -lc : lc) + ae * R + 200 * col < 28000;
+}
+
 struct PsaPackedArgs {
     PsaBatchArgs b;                 // same batch description; b.counter -> this kernel's own ticket word
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
     const uint8_t* acgt;            // per pair: 1 iff both sequences consist of the bytes A, C, G, T only (may be null)
     int32_t  elide;                 // 1: blocks that provably cannot raise the maximum run without the running max
+    int32_t  ffree;                 // 1: pure-ACGT couples run those blocks in the frame with both gap extensions free (X >= -2|E|)
 };
 
 // K1b (psa_trace_packed.hip: psa_score_bands_kernel): band pipeline over the couples of a small batch
@@ -62,6 +73,7 @@ struct PsaBandsArgs {
     int*     state;                 // [couple][W_max][packed_state_ints(R)][64]
     const uint8_t* acgt;            // per pair: 1 iff pure ACGT (may be null), as in PsaPackedArgs
     int32_t  elide;                 // as in PsaPackedArgs
+    int32_t  ffree;                 // as in PsaPackedArgs
     int64_t  rows_per_pair;         // (W_max+1) * row_stride
     int      W_max, T, d;           // bands per pair at max_len, tile length (steps), launch index
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves

@@ -102,9 +102,14 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
 // in which the VERTICAL gap costs nothing (E* = Ebar*(up)), the diagonal still costs 0 / X-M and the horizontal gap
 // 2|E|+M:  8 + 1 VALU per cell pair instead of 11.  State is converted on entry and exit (2R+5 packed adds each, per
 // 64 steps), so blocks of either kind can follow each other freely and results are identical by construction.
-template <int R, bool PERM>
+// FF ("free-free", pure-ACGT couples whose scoring has X >= -2|E|): the frame
+//     H+(i,c) = H'(i,c) + |E|*(i - top) + (|E|+M)*(c - c_ref)
+// in which BOTH gap extensions cost nothing; the diagonal then ADDS 2|E|+M (match) or 2|E|+X (mismatch, >= 0 by the
+// condition), which the column's byte table delivers directly: 7 VALU per cell pair.
+template <int R, bool PERM, bool FF = false>
 __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, const unsigned pmx, const unsigned pf2)
 {
+    static_assert(!FF || PERM, "the free-free frame needs the byte-table lookup");
     unsigned hu, eu;
     if (PERM) lane_exchange2(s.cch, s.cch2, hu, eu, s.sh, s.se, s.ach, s.ach2, s.th, s.te, s.hbot, s.ebot);
     else      lane_exchange(s.cch, hu, eu, s.sh, s.se, s.ach, s.th, s.te, s.hbot, s.ebot);
@@ -112,9 +117,9 @@ __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, con
     unsigned h = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const unsigned f = s.fb[k] - pf2;                // F* = Fbar*(left) - (2|E|+M)
+        const unsigned f = FF ? s.fb[k] : s.fb[k] - pf2; // F* = Fbar*(left) - (2|E|+M);  F+ = Fbar+(left)
         const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);
-        const unsigned dg = d - tt;
+        const unsigned dg = FF ? d + tt : d - tt;        // FF: the table holds 2|E|+M / 2|E|+X
         h = pkmax(pkmax(dg, eu), f);                     // E* = Ebar*(up): no subtraction
         const unsigned g = h - po;
         d = s.hl[k];
@@ -127,21 +132,31 @@ __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, con
     s.hd = hu;
 }
 
-// frame change H' -> H* (sign = +1) or back (sign = -1) of everything a lane carries across a block boundary;
+// The frame of the elided blocks relative to H':  + ae*(row - top row) + col*(column - reference column), minus a
+// per-band constant that centres it in the 16-bit window.  col = -|E| (H*), or |E|+M (H+, see pstep_elided<FF>).
+struct EFrame {
+    int ae, col;
+    __device__ __forceinline__ int lane_coeff(int R) const { return ae * R - col; }   // step from lane to lane
+};
+// shift of this lane's top-row entry (column t0 + ln) / of its captured bottom-row entry (column t0 - 64 + ln)
+template <int R> __device__ __forceinline__ int eframe_top_shift(const EFrame F, const int ln) { return F.col * (ln + 1) - 32 * F.lane_coeff(R); }
+template <int R> __device__ __forceinline__ int eframe_bottom_shift(const EFrame F, const int ln) { return F.ae * 64 * R + F.col * (ln - 63) - 32 * F.lane_coeff(R); }
+
+// frame change H' -> elided frame (sign = +1) or back (sign = -1) of everything a lane carries across a block boundary;
 // `after` = 0 at the block's first step, 64 after its last one (the lane has moved 64 columns to the right).
 template <int R>
-__device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const int ae, const int sign, const int after)
+__device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const EFrame F, const int sign, const int after)
 {
-    const int lane_part = (ln - 32) * (R + 1) - after;             // rows above this lane + its column lead, centred
+    const int lane_part = F.lane_coeff(R) * (ln - 32) + F.col * after;   // rows above this lane + its column lead, centred
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const int v = sign * ae * (lane_part + k + 1);
+        const int v = sign * (lane_part + F.ae * (k + 1));
         const unsigned pv = pack2(v, v);
         s.hl[k] = pkadd(s.hl[k], pv);
         s.fb[k] = pkadd(s.fb[k], pv);
     }
-    { const int v = sign * ae * lane_part;       const unsigned pv = pack2(v, v); s.hd = pkadd(s.hd, pv); }
-    { const int v = sign * ae * (lane_part + R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
+    { const int v = sign * lane_part;              const unsigned pv = pack2(v, v); s.hd = pkadd(s.hd, pv); }
+    { const int v = sign * (lane_part + F.ae * R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
 }
 
 template <int R>
@@ -181,10 +196,11 @@ __device__ __forceinline__ void bound_garbage_columns(PLane<R>& s, const int t0,
 // that no real cell ever reads and do not count.  `in_star`: the lane state is currently in the H* frame.
 template <int R, bool PARTIAL>
 __device__ __forceinline__ bool block_cannot_raise_max(const PLane<R>& s, const PairAcc& acc, const bool in_star, const int ln,
-                                                       const int ae, const int nvA, const int nvB, const bool rowsA, const bool rowsB,
+                                                       const EFrame F, const int nvA, const int nvB, const bool rowsA, const bool rowsB,
                                                        const int t0, const int M)
 {
-    const unsigned lane_s = in_star ? pack2(ae * ((ln - 32) * (R + 1)), ae * ((ln - 32) * (R + 1))) : 0u;
+    const int ae = F.ae;
+    const unsigned lane_s = in_star ? pack2(F.lane_coeff(R) * (ln - 32), F.lane_coeff(R) * (ln - 32)) : 0u;
     unsigned v = pkmax(PARTIAL ? (pksub(s.hd, lane_s) & (((nvA > 0) ? 0xffffu : 0u) | ((nvB > 0) ? 0xffff0000u : 0u))) : pksub(s.hd, lane_s),
                        PARTIAL ? (s.th & ((rowsA ? 0xffffu : 0u) | (rowsB ? 0xffff0000u : 0u))) : s.th);
 #pragma unroll

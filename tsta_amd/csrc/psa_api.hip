@@ -238,6 +238,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         ba.pe = ae | (ae << 16); ba.po = ao | (ao << 16); ba.pm = am | (am << 16); ba.pmx = amx | (amx << 16);
         ba.acgt = acgt;
+        ba.ffree = acgt && e->opt_psa_ffree != 0 && tsta::psa_ffree_ok(p->M, p->X, p->E, p->O, Rb);
         ba.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rb) + (int64_t)ae * (32 * (Rb + 1) + 192) < 28000;
         if (acgt) {
             hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,
@@ -269,6 +270,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         // the frame of the elided blocks spreads the rows of a band by |E| each: needs that much more of the 16-bit window
         pa.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rp) + (int64_t)ae * (32 * (Rp + 1) + 192) < 28000;
         pa.acgt = acgt;
+        pa.ffree = acgt && e->opt_psa_ffree != 0 && tsta::psa_ffree_ok(p->M, p->X, p->E, p->O, Rp);
         if (acgt) {
             hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,
                                d_seqs, d_off1, d_len1, d_off2, d_len2, n_pairs, reinterpret_cast<uint8_t*>(e->pair_flags.p));

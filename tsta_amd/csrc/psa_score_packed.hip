@@ -25,7 +25,7 @@ namespace tsta {
 
 // The two pairs of a couple may differ in size: the wave sweeps max(nA,nB) columns and max(mA,mB) rows; cells
 // outside the smaller pair compute garbage that only feeds other such cells and is masked out of its running max.
-template <int R, bool PARTIAL, bool PERM>
+template <int R, bool PARTIAL, bool PERM, bool FF>
 __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int nA, const int nB,
                                       const uint8_t* __restrict__ bA, const uint8_t* __restrict__ bB, const int mA, const int mB,
                                       const bool store_bottom,
@@ -72,6 +72,8 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
 
     const int nsteps = n + 64;
     const int ae = -E;
+    const EFrame F = {ae, FF ? ae + M : -ae};      // frame of the elided blocks: H+ (both gap extensions free) or H*
+    const unsigned cm4 = (unsigned)(2 * ae + M) * 0x01010101u;   // FF: table of diagonal ADDENDS = cm4 - table of mismatch costs
     bool in_star = false;        // lane state currently in the frame of the elided blocks (kept across consecutive ones)
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
         const int ln = opaque(lane);
@@ -83,7 +85,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
             const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
             // (in the H* frame the reference column moves along with the block: +64|E| on everything)
-            const int star = in_star ? 64 * ae : 0;
+            const int star = in_star ? -64 * F.col : 0;
             const unsigned pd = pack2(nbA - acc.baseA - star, nbB - acc.baseB - star);
             acc.baseA = nbA; acc.baseB = nbB;
             lag = 0;
@@ -102,27 +104,31 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
             s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
         }
-        if (PERM) { s.ach = acgt_table(naA, k4); s.ach2 = acgt_table(naB, k4); }
-        else      s.ach = pack2(naA << 8, naB << 8);
+        unsigned tabA = 0u, tabB = 0u;                 // this block's column tables (PERM) / characters
+        if (PERM) { tabA = acgt_table(naA, k4); tabB = acgt_table(naB, k4); }
+        else      tabA = pack2(naA << 8, naB << 8);
         const int cn = t0 + 64 + ln;
         if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
         if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
         bool elide = false;
         if (steady && elide_ok) {
-            elide = block_cannot_raise_max<R, PARTIAL>(s, acc, in_star, ln, ae, nvA, nvB, mA > band_row0, mB > band_row0, t0, M);
+            elide = block_cannot_raise_max<R, PARTIAL>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M);
         }
         if (elide != in_star) {                        // frame change only where the kind of block changes
-            if (elide) elided_frame<R>(s, ln, ae, +1, 0);
-            else       elided_frame<R>(s, ln, ae, -1, lag);
+            if (elide) elided_frame<R>(s, ln, F, +1, 0);
+            else       elided_frame<R>(s, ln, F, -1, lag);
+            if (FF) { s.cch = cm4 - s.cch; s.cch2 = cm4 - s.cch2; }   // the column tables under way change meaning with the frame
             in_star = elide;
         }
+        if (PERM) { s.ach = (FF && elide) ? cm4 - tabA : tabA; s.ach2 = (FF && elide) ? cm4 - tabB : tabB; }
+        else      s.ach = tabA;
         if (elide) {
-            { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+            { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
+            for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF>(s, po, pmx, pf2);
             // the 64 captured bottom-row entries (column t0-64+lane): row 64R below the top, 63-lane columns behind t0-1
-            { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
+            { const int v = -eframe_bottom_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if (steady) {
 #pragma unroll 2
             for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
@@ -141,7 +147,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     fold_max<R>(s, acc);
 }
 
-template <int R, bool PERM>
+template <int R, bool PERM, bool FF>
 __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
                                               int nA, int mA, int nB, int mB, int2* rowA, int2* rowB, int lane,
                                               int M, int E, int O,
@@ -159,8 +165,8 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     constexpr int BAND = 64 * R;
     for (int r0 = 0; r0 < mmax; r0 += BAND) {
         const bool last = r0 + BAND >= mmax;
-        if (r0 + BAND <= mmin) pband<R, false, PERM>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-        else                   pband<R, true, PERM>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        if (r0 + BAND <= mmin) pband<R, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        else                   pband<R, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
         if (!last) wave_mem_sync();
     }
     outA = wave_max(acc.mxA);
@@ -195,8 +201,9 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         int ra, rb;
         // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
         const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
-        if (perm) pscore_couple<R, true>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
-        else      pscore_couple<R, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
+        if (perm && P.ffree) pscore_couple<R, true, true>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
+        else if (perm)       pscore_couple<R, true, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
+        else                 pscore_couple<R, false, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
         wave_mem_sync();
     }

@@ -154,7 +154,7 @@ struct CoupleView {
 };
 
 // steps [s0, s1) of one band of one couple
-template <int R, bool TRACE, bool PERM>
+template <int R, bool TRACE, bool PERM, bool FF = false>
 __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
                                             const int M, const int E, const int O,
                                             const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
@@ -173,6 +173,9 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     const unsigned pf2 = pf + pe;                  // horizontal gap in the frame of the elided blocks
     const unsigned k4 = (pmx_s & 0xffu) * 0x01010101u;
     const int ae = -E;
+    static_assert(!FF || (PERM && !TRACE), "free-free frame: score-only tiles of pure-ACGT couples");
+    const EFrame F = {ae, FF ? ae + M : -ae};      // frame of the elided blocks (packed_step.h)
+    const unsigned cm4 = (unsigned)(2 * ae + M) * 0x01010101u;
     constexpr int BAND = 64 * R;
     const int band_row0 = w * BAND;
     const bool partial = band_row0 + BAND > mmin;
@@ -249,7 +252,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
             const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
             // (in the H* frame the reference column moves along with the block: +64|E| on everything)
-            const int star = in_star ? 64 * ae : 0;
+            const int star = in_star ? -64 * F.col : 0;
             const unsigned pd = pack2(nbA - acc.baseA - star, nbB - acc.baseB - star);
             lag = 0;
             acc.baseA = nbA; acc.baseB = nbB;
@@ -267,8 +270,9 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
             s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
         }
-        if (PERM) { s.ach = acgt_table(naA, k4); s.ach2 = acgt_table(naB, k4); }
-        else      s.ach = pack2(naA << 8, naB << 8);
+        unsigned tabA = 0u, tabB = 0u;                 // this block's column tables (PERM) / characters
+        if (PERM) { tabA = acgt_table(naA, k4); tabB = acgt_table(naB, k4); }
+        else      tabA = pack2(naA << 8, naB << 8);
         if (t0 + 64 < s1) {
             const int cn = t0 + 64 + ln;
             ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
@@ -284,22 +288,25 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         // blocks that provably cannot raise either maximum run without the running max, in the H* frame (packed_step.h)
         bool elide = false;
         if (steady && elide_ok)
-            elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, ae, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
-                            : block_cannot_raise_max<R, false>(s, acc, in_star, ln, ae, nvA, nvB, true, true, t0, M);
+            elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
+                            : block_cannot_raise_max<R, false>(s, acc, in_star, ln, F, nvA, nvB, true, true, t0, M);
         if (elide != in_star) {                        // frame change only where the kind of block changes
-            if (elide) elided_frame<R>(s, ln, ae, +1, 0);
-            else       elided_frame<R>(s, ln, ae, -1, lag);
+            if (elide) elided_frame<R>(s, ln, F, +1, 0);
+            else       elided_frame<R>(s, ln, F, -1, lag);
+            if (FF) { s.cch = cm4 - s.cch; s.cch2 = cm4 - s.cch2; }   // the column tables under way change meaning with the frame
             in_star = elide;
         }
+        if (PERM) { s.ach = (FF && elide) ? cm4 - tabA : tabA; s.ach2 = (FF && elide) ? cm4 - tabB : tabB; }
+        else      s.ach = tabA;
         if (elide) {
-            { const int v = -ae * (ln + 1 + 32 * (R + 1)); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+            { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
             if constexpr (TRACE) {
                 ptblock<R, false, false, PERM, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf2, K, tqA, tqB);
             } else {
 #pragma unroll 2
-                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM>(s, po, pmx, pf2);
+                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF>(s, po, pmx, pf2);
             }
-            { const int v = -ae * (64 * R + 63 - ln - 32 * (R + 1)); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
+            { const int v = -eframe_bottom_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if constexpr (TRACE) {
             if (!steady && nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);   // beyond the shorter job's end: keep its half in range
             if (steady && !partial)      ptblock<R, false, false, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
@@ -434,8 +441,9 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     V.w = w;
     // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
     const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
-    if (perm) packed_tile<R, false, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
-    else      packed_tile<R, false, false>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    if (perm && P.ffree) packed_tile<R, false, true, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    else if (perm)       packed_tile<R, false, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    else                 packed_tile<R, false, false>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
 }
 
 // per couple (blockIdx.x): out[pair] = max over the bands' lanes, floored at -100 (psa.c:110,590)
