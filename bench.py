@@ -2,7 +2,9 @@
 """bench.py — GCUPS of batched 50 kbp x 50 kbp global affine-gap alignment (score only) on N MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run, one rank
-per GPU.  A "step" = one pass of the hot path (tsta_psa_score_batch_dev through the C-ABI) over this rank's shard
+per GPU — or by itself: run as plain `python bench.py --gpus N` (no RANK in the environment) it starts that launcher as
+a CHILD process before touching the GPU and relays rank 0's JSON line.  Every rank asserts WORLD_SIZE == --gpus, and the
+line carries `ranks_seen` (distinct device UUIDs, all-gathered).  A "step" = one pass of the hot path (tsta_psa_score_batch_dev through the C-ABI) over this rank's shard
 of the batch, inputs already resident in HBM, followed (N>1) by the RCCL all-gather of the int32 scores — the only
 collective on the path.  Workload = BASELINE.json config #5 per-GPU shard (independent pairs, weak scaling):
 PAIRS_PER_GPU pairs of LEN x LEN random DNA per GPU, default scoring (M=2 X=-5 E=-2 O=-4).
@@ -46,18 +48,21 @@ def parse():
     ap.add_argument("--len", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generic", action="store_true", help="skip the extra pass down the generic kernel path")
+    ap.add_argument("--no-related", action="store_true", help="skip the extra pass over related (5 %% divergent) pairs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of sampled scores against the reference / oracle")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
 
 
-def make_shard(n_pairs, length, seed, device):
+def make_shard(n_pairs, length, seed, device, related=None):
     """Synthetic iid uniform ACGT, generated on the GPU (inputs are HBM-resident before the timed region).
     TSTA_BENCH_RELATED=<percent> (experiments only, not the BASELINE workload): the second sequence of every pair is the
     first with that percentage of substituted positions instead of an independent draw."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     idx = torch.randint(0, 4, (2 * n_pairs * length,), generator=g, device=device, dtype=torch.uint8)
-    related = float(os.environ.get("TSTA_BENCH_RELATED", 0))
+    if related is None:
+        related = float(os.environ.get("TSTA_BENCH_RELATED", 0))
     if related > 0:
         v = idx.view(n_pairs, 2, length)
         for lo in range(0, n_pairs, 256):
@@ -74,6 +79,131 @@ def make_shard(n_pairs, length, seed, device):
     off2 = off1 + length
     ln = torch.full((n_pairs,), length, dtype=torch.int32, device=device)
     return seqs, off1, ln, off2, ln.clone()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N>1) without a launcher: start torch.distributed.run as a CHILD process — before this
+    process has made any GPU call; a process that has initialised the GPU must never exec another — let it print rank 0's
+    JSON line on our stdout, and exit with its code."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def run_reference(binary, threads, fa, fb, limit=120.0, tries=3):
+    """One TSTA_psa_notrace process -> its stdout.  The reference's thread pool can deadlock (no join, unlocked shutdown
+    flag: pthreadpool.c:96-117; seen here under oversubscription), so every run has a time limit and is retried."""
+    last = None
+    for _ in range(tries):
+        try:
+            r = subprocess.run([binary, "-T", str(threads), "-1", fa, "-2", fb], capture_output=True, check=True, timeout=limit)
+            if b"maxsorce=" in r.stdout:
+                return r.stdout
+            last = RuntimeError("no maxsorce in output")
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as ex:
+            last = ex
+    raise last
+
+
+def reference_binary():
+    """oracle/_ref/TSTA_psa_notrace (the unmodified reference compiled by oracle/Makefile) if this host can run it."""
+    from tests import util
+    for name, flag in (("TSTA_psa_notrace", "avx512bw"), ("TSTA_psa_notrace_avx2", "avx2")):
+        b = os.path.join(util.REF_DIR, name)
+        if os.path.exists(b) and util.cpu_has(flag):
+            return b
+    return None
+
+
+def reference_scores(pairs, cores):
+    """maxsorce (psa.c:666) of every (a, b) pair of uint8 arrays as the REFERENCE computes it: its own binary, one process
+    per pair; where that binary cannot run, the scalar oracle port.  -> (scores, "reference" | "port")"""
+    from tests import util
+    binary = reference_binary()
+    if binary:
+        try:
+            got = []
+            with tempfile.TemporaryDirectory() as td:
+                for i, (a, b) in enumerate(pairs):
+                    fa, fb = os.path.join(td, "a%d.fa" % i), os.path.join(td, "b%d.fa" % i)
+                    util.write_fasta(fa, "a", a); util.write_fasta(fb, "b", b)
+                    so = run_reference(binary, min(cores, 64), fa, fb)
+                    got.append(int(so.decode().split("maxsorce=")[1].split()[0]))
+            return got, "reference"
+        except Exception as ex:
+            sys.stderr.write("reference_scores: reference binary failed (%r); using the oracle port\n" % (ex,))
+    return [int(x) for x in util.oracle_maxscore_batch(pairs, threads=cores)], "port"
+
+
+def verify_against_reference(seqs, off1, len1, off2, len2, scores, picks, cores):
+    """D2H the sequences of the picked pairs of the shard that was just timed and require the reference's maxsorce for
+    each of them to equal the kernel's."""
+    pairs = []
+    for k in picks:
+        a = seqs[int(off1[k]):int(off1[k]) + int(len1[k])].cpu().numpy()
+        b = seqs[int(off2[k]):int(off2[k]) + int(len2[k])].cpu().numpy()
+        pairs.append((a, b))
+    want, kind = reference_scores(pairs, cores)
+    got = [int(scores[k]) for k in picks]
+    assert got == want, "kernel scores differ from the %s on pairs %s: %s vs %s" % (kind, picks, got, want)
+    return {"verified_pairs": len(picks), "verified_by": kind, "pairs": [int(k) for k in picks], "scores": got}
+
+
+def cpu_throughput(length, cores, seed=777):
+    """The reference used for THROUGHPUT rather than latency: k concurrent TSTA_psa_notrace processes with -T cores/k
+    each (one 79-block anti-diagonal cannot feed hundreds of threads).  Best of k in {cores/32, cores/8} (>=1)."""
+    from tests import util
+    binary = reference_binary()
+    if not binary:
+        return None
+    best = None
+    with tempfile.TemporaryDirectory() as td:
+        n_files = 8
+        files = []
+        for i in range(n_files):
+            fa, fb = os.path.join(td, "a%d.fa" % i), os.path.join(td, "b%d.fa" % i)
+            util.write_fasta(fa, "a", util.random_dna(seed + 2 * i, length)); util.write_fasta(fb, "b", util.random_dna(seed + 2 * i + 1, length))
+            files.append((fa, fb))
+        for k in sorted({max(1, cores // 32), max(1, cores // 8), max(1, cores // 2)}):
+            t_each = max(1, cores // k)
+            # calibrate on one lone run, then every worker (a shell loop: no Python between its runs) aligns `reps` pairs
+            # back to back, about 8 s of work each
+            c0 = time.perf_counter()
+            try:
+                run_reference(binary, t_each, files[0][0], files[0][1], limit=60.0)
+            except Exception:
+                continue
+            one = max(1e-3, time.perf_counter() - c0)
+            reps = int(min(256, max(2, round(8.0 / one))))
+            limit = max(5.0, 20.0 * one)            # a run that takes this long has deadlocked: it is killed and not counted
+            procs = []
+            t0 = time.perf_counter()
+            for w in range(k):
+                fa, fb = files[w % n_files]
+                sh = ("n=0; for i in $(seq %d); do timeout -k 2 %.0f %s -T %d -1 %s -2 %s > /dev/null && n=$((n+1)); done; echo $n"
+                      % (reps, limit, binary, t_each, fa, fb))
+                procs.append(subprocess.Popen(["sh", "-c", sh], stdout=subprocess.PIPE))
+            done = 0
+            for pr in procs:
+                so, _ = pr.communicate()
+                try:
+                    done += int(so.decode().strip() or 0)
+                except ValueError:
+                    pass
+            dt = time.perf_counter() - t0
+            if done == 0:
+                continue
+            v = float(done) * length * length / dt / 1e9
+            if best is None or v > best["value"]:
+                best = {"value": v, "unit": "GCUPS", "cores": cores, "kind": "reference",
+                        "sample": "%d concurrent oracle/_ref/%s -T %d processes x %d pairs of %dx%d each, %.1f s; %d of %d runs "
+                                  "completed (the reference's thread pool can deadlock: such runs are killed at %.0f s)"
+                                  % (k, os.path.basename(binary), t_each, reps, length, length, dt, done, k * reps, limit)}
+    return best
 
 
 def cpu_baseline(length, sample_pairs, seed=12345):
@@ -101,16 +231,13 @@ def cpu_baseline(length, sample_pairs, seed=12345):
                     fa, fb = os.path.join(td, "a%d.fa" % i), os.path.join(td, "b%d.fa" % i)
                     util.write_fasta(fa, "a", a); util.write_fasta(fb, "b", b)
                     files.append((fa, fb))
-                subprocess.run([binary, "-T", str(cores), "-1", files[0][0], "-2", files[0][1]], capture_output=True,
-                               check=True, timeout=600)     # warm-up (page in the binary)
+                run_reference(binary, cores, files[0][0], files[0][1])     # warm-up (page in the binary)
                 # repeat the sample until about TARGET_S seconds of CPU work have been timed (bounded)
                 t0 = time.perf_counter()
                 done = 0
                 while True:
                     for fa, fb in files:
-                        r = subprocess.run([binary, "-T", str(cores), "-1", fa, "-2", fb], capture_output=True,
-                                           check=True, timeout=600)
-                        assert b"maxsorce=" in r.stdout
+                        run_reference(binary, cores, fa, fb)
                     done += len(files)
                     dt = time.perf_counter() - t0
                     if dt >= 12.0 or done >= 4096:
@@ -133,8 +260,11 @@ def cpu_baseline(length, sample_pairs, seed=12345):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run `python bench.py --gpus N` directly)" % (args.gpus, world)
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     # rehearsal of the N>1 control flow on a box with ONE GPU (never used by the driver): every rank computes on device 0
     # and the collectives run over gloo on host copies.  Numbers from such a run mean nothing.
@@ -193,6 +323,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # which devices took part: all-gather of the 16-byte device UUIDs (a rehearsal on one GPU shows ONE distinct UUID)
+    uuid = tsta_amd.device_uuid(local_rank)
+    uuids = [uuid]
+    if world > 1:
+        u = torch.tensor(list(bytes.fromhex(uuid)), dtype=torch.uint8, device="cpu" if rehearsal else dev)
+        allu = torch.empty(16 * world, dtype=torch.uint8, device=u.device)
+        dist.all_gather_into_tensor(allu, u)
+        uuids = [bytes(allu[16 * r:16 * r + 16].cpu().tolist()).hex() for r in range(world)]
+        assert gathered[0] is not None and gathered[0].numel() == P * world
+        assert torch.equal(gathered[0][rank * P:(rank + 1) * P].to(scores.device), scores), "gathered scores differ from this rank's shard"
 
     # the same shard once more down the generic path (any byte alphabet, running max kept in every block): what the
     # kernel does when neither of its two data-dependent shortcuts applies.  Results must be identical.
@@ -213,6 +353,42 @@ def main():
     # sanity on the result of the last step: random DNA gives a degenerate maxsorce in a tiny range
     sc = scores.cpu().numpy()
     assert sc.min() >= -100 and sc.max() < 2 * L, (sc.min(), sc.max())
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+
+    # the scores of the shard that was just timed, tied to the reference (psa.c:666): a few of its pairs go back to the host
+    # and through oracle/_ref/TSTA_psa_notrace (the scalar oracle port where that binary cannot run)
+    verified = None
+    if rank == 0 and not args.no_verify:
+        picks = sorted({0, 1, P // 2, P - 1} & set(range(P)))
+        verified = verify_against_reference(seqs, off1.cpu().numpy(), len1.cpu().numpy(), off2.cpu().numpy(), len2.cpu().numpy(), sc, picks, cores)
+
+    # a shard of RELATED pairs (second sequence = first with 5 % substitutions): real workloads are not iid DNA; the
+    # running-max elision then applies to every band except those the high-scoring diagonal crosses
+    related = None
+    if world == 1 and not args.no_related:
+        del seqs
+        torch.cuda.empty_cache()
+        rseqs, roff1, rlen1, roff2, rlen2 = make_shard(P, L, 5000 + rank, dev, related=5.0)
+        rscores = torch.empty(P, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(tstream):
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(2):
+                if i == 1:
+                    r0.record()
+                eng.psa_score_batch_dev(params, P, rseqs.data_ptr(), roff1.data_ptr(), rlen1.data_ptr(), roff2.data_ptr(),
+                                        rlen2.data_ptr(), rscores.data_ptr(), L, stream)
+            r1.record()
+            torch.cuda.synchronize()
+        related = {"value": float(P) * L * L / (r0.elapsed_time(r1) * 1e-3) / 1e9, "unit": "GCUPS", "ms": r0.elapsed_time(r1),
+                   "note": "same kernel, %d pairs of %d x %d where the second sequence is the first with 5 %% substitutions" % (P, L, L)}
+        if not args.no_verify:
+            rsc = rscores.cpu().numpy()
+            related.update(verify_against_reference(rseqs, roff1.cpu().numpy(), rlen1.cpu().numpy(), roff2.cpu().numpy(),
+                                                    rlen2.cpu().numpy(), rsc, sorted({0, P - 1}), cores))
+        del rseqs
 
     if rank == 0:
         cells_per_step = float(P) * world * L * L
@@ -257,6 +433,13 @@ def main():
                               "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
                               "frac": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS},
         }
+        out["ranks_seen"] = len(set(uuids))
+        out["device_uuids"] = uuids
+        out["build_info"] = tsta_amd.build_info()
+        if verified is not None:
+            out.update(verified)
+        if related is not None:
+            out["related_path"] = related
         if generic_ms is not None:
             out["generic_path"] = {"value": float(P) * L * L / (generic_ms * 1e-3) / 1e9, "unit": "GCUPS", "ms": generic_ms,
                                    "ops_per_cell": VALU_OPS_PER_CELL_GENERIC,
@@ -264,6 +447,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             n_s = args.cpu_sample_pairs or min(256, max(4, int(round(16 * (50_000.0 / L) ** 2))))
             out["cpu_baseline"] = cpu_baseline(L, n_s)
+            thr = cpu_throughput(L, out["cpu_baseline"]["cores"])
+            if thr is not None:
+                out["cpu_baseline_throughput"] = thr
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -175,6 +175,49 @@ int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* d
                    int32_t n, tsta_poa_step** steps, int64_t* n_steps, int32_t* end_col, int32_t* lastscore);
 
 /* ------------------------------------------------------------------------------------------------
+ * Several GPUs of one node  ==  the reference's ONE driver loop over the blocks of ONE pair (psa.c:619-639) turned
+ * into the sharding of a BATCH of independent pairs (north_star / SURVEY 8e): contiguous ranges of pairs per device,
+ * balanced by DP cells; one host thread + one engine per device; no data-path collective.  The only exchange is the
+ * final gather of the int32 scores (4 B per pair):
+ *   "gather" = 0 (default)  every device copies its shard straight into out[lo..hi) (single process: the shortest way)
+ *   "gather" = 1            RCCL all-gather over xGMI (ncclCommInitAll + one grouped ncclAllGather of int32, librccl is
+ *                           dlopen'ed on first use): every device ends up with all n_pairs scores, device 0's copy goes to out
+ *   "gather" = 2            as 1, and every device's gathered copy is read back and compared (tests)
+ * devices = NULL -> devices 0..n_dev-1; n_dev = 0 -> every device of the node.  A tsta_multi is used by one host thread at a time.
+ * Per-engine tuning knobs: tsta_engine_set_option(tsta_multi_engine(m, i), ...).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct tsta_multi tsta_multi;
+int  tsta_multi_create(const int* devices, int n_dev, tsta_multi** out);
+void tsta_multi_destroy(tsta_multi* m);
+int  tsta_multi_device_count(const tsta_multi* m);
+tsta_engine* tsta_multi_engine(tsta_multi* m, int i);      /* engine of the i-th device (NULL if out of range) */
+const char*  tsta_multi_last_error(const tsta_multi* m);
+int  tsta_multi_set_option(tsta_multi* m, const char* key, int64_t value);   /* "gather": 0 | 1 | 2 */
+
+/* bounds[0..n_shards]: shard s = pairs [bounds[s], bounds[s+1]); contiguous, cut where the running sum of
+ * len1[k]*len2[k] (+1 per pair, so that empty pairs spread too) crosses s/n_shards of the total.  Equal-size pairs
+ * give shards that differ by at most one pair.  Pure host arithmetic (no device needed). */
+int  tsta_shard_bounds(int64_t n_pairs, const int32_t* len1, const int32_t* len2, int n_shards, int64_t* bounds);
+
+/* tsta_psa_score_batch / tsta_psa_align_batch over all devices of `m` (same arguments, same results).  Each device
+ * receives only the byte range of `seqs` its shard refers to. */
+int  tsta_psa_score_batch_multi(tsta_multi* m, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                                int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                                const int64_t* off2, const int32_t* len2, int32_t* out);
+int  tsta_psa_align_batch_multi(tsta_multi* m, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                                int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                                const int64_t* off2, const int32_t* len2, tsta_alignment* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Identification.  tsta_build_info(): "libtsta_hip <16 hex digits> gfx950" where the digits are the first 64 bits
+ * of the SHA-256 over the library's sources (the .hip and .h files of tsta_amd/csrc in name order, then this header) as they
+ * were when THIS binary was compiled; tsta_amd/lib/BUILD_INFO holds the same line.  A stale shipped .so shows as a
+ * mismatch with the sources next to it (tests/test_abi.py).  tsta_device_uuid(): 32 hex digits + NUL into out[33].
+ * ------------------------------------------------------------------------------------------------ */
+const char* tsta_build_info(void);
+int  tsta_device_uuid(int device, char* out33);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): duration of the kernels of the last *_dev / host call, measured with HIP
  * events on the stream they ran on, and the number of kernel launches it took.
  * ------------------------------------------------------------------------------------------------ */

@@ -67,3 +67,31 @@ def test_pack_2bit_is_a_host_function():
     assert dst.tolist() == want
     bad = np.frombuffer(b"ACNT", dtype=np.uint8)
     assert lib.tsta_pack_2bit(bad.ctypes.data_as(C.c_void_p), 4, dst.ctypes.data_as(C.c_void_p)) == -5      # TSTA_ERR_UNSUPPORTED
+
+
+def test_build_info_matches_the_sources_in_the_tree(built_lib):
+    # a stale libtsta_hip.so (built from other sources than the ones next to it) shows here and on the GPU box
+    info = tsta_amd.build_info()
+    assert info == "libtsta_hip %s gfx950" % tsta_amd.source_hash(), info
+    with open(os.path.join(util.ROOT, "tsta_amd", "lib", "BUILD_INFO")) as f:
+        assert f.read().strip() == info
+
+
+def test_shard_bounds_is_a_host_function():
+    # tsta_shard_bounds (multi-GPU partition of a batch): contiguous, covers the batch, balanced by DP cells
+    import numpy as np
+    for n in (0, 1, 7, 8192, 65536):
+        for w in (1, 2, 3, 8):
+            ln = np.full(n, 50_000, dtype=np.int32)
+            b = tsta_amd.shard_bounds(ln, ln, w)
+            assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0)
+            assert np.diff(b).max() - np.diff(b).min() <= 1, (n, w, b)
+    rng = np.random.default_rng(5)
+    l1 = rng.integers(0, 60_000, 1000).astype(np.int32); l2 = rng.integers(0, 60_000, 1000).astype(np.int32)
+    cells = l1.astype(np.int64) * l2 + 1
+    for w in (2, 5, 8):
+        b = tsta_amd.shard_bounds(l1, l2, w)
+        per = np.array([cells[b[s]:b[s + 1]].sum() for s in range(w)])
+        assert b[0] == 0 and b[-1] == 1000
+        assert per.max() - per.min() <= 2 * cells.max(), (w, per)
+    assert tsta_amd.lib().tsta_shard_bounds(1, None, None, 2, None) == -1        # TSTA_ERR_INVALID_ARG

@@ -9,7 +9,8 @@ import os
 
 import numpy as np
 
-__all__ = ["TstaError", "Params", "Engine", "lib", "lib_path", "build", "EXPORTED_SYMBOLS"]
+__all__ = ["TstaError", "Params", "Engine", "Multi", "lib", "lib_path", "build", "build_info", "source_hash", "device_uuid",
+           "shard_bounds", "EXPORTED_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(_HERE, "lib", "libtsta_hip.so")
@@ -20,6 +21,9 @@ EXPORTED_SYMBOLS = [
     "tsta_free", "tsta_psa_score_batch", "tsta_psa_score_batch_dev", "tsta_psa_align", "tsta_poa_fill",
     "tsta_last_kernel_ms", "tsta_engine_set_option", "tsta_poa_align", "tsta_psa_align_batch", "tsta_alignments_free",
     "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit", "tsta_engine_release_workspaces",
+    "tsta_multi_create", "tsta_multi_destroy", "tsta_multi_device_count", "tsta_multi_engine", "tsta_multi_last_error",
+    "tsta_multi_set_option", "tsta_shard_bounds", "tsta_psa_score_batch_multi", "tsta_psa_align_batch_multi",
+    "tsta_build_info", "tsta_device_uuid",
 ]
 
 
@@ -98,6 +102,19 @@ def lib():
                                      C.POINTER(i32), vp]
         L.tsta_last_kernel_ms.restype = C.c_int
         L.tsta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+        L.tsta_build_info.restype = C.c_char_p; L.tsta_build_info.argtypes = []
+        L.tsta_device_uuid.restype = C.c_int; L.tsta_device_uuid.argtypes = [C.c_int, C.c_char_p]
+        L.tsta_shard_bounds.restype = C.c_int; L.tsta_shard_bounds.argtypes = [i64, vp, vp, C.c_int, vp]
+        L.tsta_multi_create.restype = C.c_int; L.tsta_multi_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.tsta_multi_destroy.restype = None; L.tsta_multi_destroy.argtypes = [vp]
+        L.tsta_multi_device_count.restype = C.c_int; L.tsta_multi_device_count.argtypes = [vp]
+        L.tsta_multi_engine.restype = vp; L.tsta_multi_engine.argtypes = [vp, C.c_int]
+        L.tsta_multi_last_error.restype = C.c_char_p; L.tsta_multi_last_error.argtypes = [vp]
+        L.tsta_multi_set_option.restype = C.c_int; L.tsta_multi_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.tsta_psa_score_batch_multi.restype = C.c_int
+        L.tsta_psa_score_batch_multi.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, vp]
+        L.tsta_psa_align_batch_multi.restype = C.c_int
+        L.tsta_psa_align_batch_multi.argtypes = [vp, C.POINTER(Params), i64, vp, i64, vp, vp, vp, vp, C.POINTER(Alignment)]
         _lib = L
     return _lib
 
@@ -118,6 +135,112 @@ def pack_pairs(pairs):
     seqs = np.concatenate(flat) if pos else np.zeros(0, dtype=np.uint8)
     return (np.ascontiguousarray(seqs), np.array(o1, dtype=np.int64), np.array(l1, dtype=np.int32),
             np.array(o2, dtype=np.int64), np.array(l2, dtype=np.int32))
+
+
+def build_info():
+    """'libtsta_hip <hash> gfx950' of the loaded library (tsta_build_info)."""
+    return lib().tsta_build_info().decode()
+
+
+def source_hash():
+    """The hash tsta_amd/csrc/Makefile computes over the sources as they are NOW in the tree (a library built from
+    other sources reports a different one through build_info())."""
+    import glob
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    with open(os.path.join(src, "Makefile")) as f:
+        srcs = next(l for l in f if l.startswith("SRCS")).split(":=")[1].split()
+    names = sorted(set(srcs) | {os.path.basename(h) for h in glob.glob(os.path.join(src, "*.h"))})
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(src, n), "rb") as f:
+            h.update(f.read())
+    with open(os.path.join(_HERE, "..", "include", "tsta_engine.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def device_uuid(device=0):
+    buf = C.create_string_buffer(33)
+    rc = lib().tsta_device_uuid(int(device), buf)
+    if rc != 0:
+        raise TstaError("tsta_device_uuid(%d): %s" % (device, lib().tsta_strerror(rc).decode()))
+    return buf.value.decode()
+
+
+def shard_bounds(len1, len2, n_shards):
+    """tsta_shard_bounds: contiguous shards balanced by DP cells -> int64 array of n_shards + 1 bounds."""
+    len1 = np.ascontiguousarray(len1, dtype=np.int32); len2 = np.ascontiguousarray(len2, dtype=np.int32)
+    b = np.zeros(n_shards + 1, dtype=np.int64)
+    z = np.zeros(1, dtype=np.int32)
+    rc = lib().tsta_shard_bounds(len(len1), _ptr(len1 if len(len1) else z), _ptr(len2 if len(len2) else z), int(n_shards), _ptr(b))
+    if rc != 0:
+        raise TstaError("tsta_shard_bounds: %s" % lib().tsta_strerror(rc).decode())
+    return b
+
+
+class Multi:
+    """Several GPUs of one node (mirrors ``tsta_multi``): a batch is sharded over the devices, one engine each."""
+
+    def __init__(self, devices=None, n_dev=0):
+        self._h = C.c_void_p()
+        arr = None
+        if devices is not None:
+            arr = np.ascontiguousarray(devices, dtype=np.int32); n_dev = len(arr)
+        rc = lib().tsta_multi_create(_ptr(arr) if arr is not None else None, int(n_dev), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise TstaError("tsta_multi_create: %s" % lib().tsta_strerror(rc).decode())
+        self.n_dev = lib().tsta_multi_device_count(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().tsta_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise TstaError("%s: %s (%s)" % (what, lib().tsta_strerror(rc).decode(), lib().tsta_multi_last_error(self._h).decode()))
+
+    def set_option(self, key, value):
+        self._check(lib().tsta_multi_set_option(self._h, key.encode(), int(value)), "tsta_multi_set_option(%s)" % key)
+
+    def set_engine_option(self, key, value):
+        for i in range(self.n_dev):
+            rc = lib().tsta_engine_set_option(lib().tsta_multi_engine(self._h, i), key.encode(), int(value))
+            self._check(rc, "tsta_engine_set_option(%s)" % key)
+
+    def psa_score_batch(self, pairs, params=None):
+        params = params or Params()
+        out = np.zeros(len(pairs), dtype=np.int32)
+        if len(pairs) == 0:
+            return out
+        seqs, o1, l1, o2, l2 = pack_pairs(pairs)
+        sq = seqs if len(seqs) else np.zeros(1, dtype=np.uint8)
+        rc = lib().tsta_psa_score_batch_multi(self._h, C.byref(params), len(pairs), _ptr(sq), len(seqs), _ptr(o1), _ptr(l1),
+                                              _ptr(o2), _ptr(l2), _ptr(out))
+        self._check(rc, "tsta_psa_score_batch_multi")
+        return out
+
+    def psa_align_batch(self, pairs, params=None):
+        params = params or Params()
+        if len(pairs) == 0:
+            return []
+        seqs, o1, l1, o2, l2 = pack_pairs(pairs)
+        sq = seqs if len(seqs) else np.zeros(1, dtype=np.uint8)
+        out = (Alignment * len(pairs))()
+        rc = lib().tsta_psa_align_batch_multi(self._h, C.byref(params), len(pairs), _ptr(sq), len(seqs), _ptr(o1), _ptr(l1),
+                                              _ptr(o2), _ptr(l2), out)
+        self._check(rc, "tsta_psa_align_batch_multi")
+        res = [(int(o.maxscore), C.string_at(o.row_a, o.len), C.string_at(o.row_b, o.len)) for o in out]
+        lib().tsta_alignments_free(out, len(pairs))
+        return res
 
 
 class Engine:

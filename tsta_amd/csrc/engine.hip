@@ -69,6 +69,24 @@ const char* tsta_last_error(const tsta_engine* eng)
     return eng ? reinterpret_cast<const Engine*>(eng)->err : "";
 }
 
+#ifndef TSTA_SRC_HASH
+#error "build through tsta_amd/csrc/Makefile: it passes -DTSTA_SRC_HASH (SHA-256 of the sources)"
+#endif
+const char* tsta_build_info(void) { return "libtsta_hip " TSTA_SRC_HASH " gfx950"; }
+
+int tsta_device_uuid(int device, char* out33)
+{
+    if (!out33) return TSTA_ERR_INVALID_ARG;
+    out33[0] = 0;
+    const int n = tsta_device_count();
+    if (n <= 0) return TSTA_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return TSTA_ERR_INVALID_ARG;
+    hipUUID u;
+    if (hipDeviceGetUuid(&u, device) != hipSuccess) { (void)hipGetLastError(); return TSTA_ERR_HIP; }
+    for (int i = 0; i < 16; ++i) snprintf(out33 + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+    return TSTA_OK;
+}
+
 int tsta_device_count(void)
 {
     int n = 0;

@@ -92,6 +92,10 @@ namespace tsta {
 // psa_trace.hip: score-only fill of ONE oriented pair pipelined over many waves (host pointers; synchronous)
 int psa_score_single_pair(Engine* e, const tsta_params* p, const uint8_t* a, int n, const uint8_t* b, int m, int32_t* maxscore);
 void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream);
+// psa_api.hip: tsta_psa_score_batch proper; with d_scores the scores (also) stay on the device (multi.hip gathers them)
+int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs, int64_t seqs_bytes,
+                         const int64_t* off1, const int32_t* len1, const int64_t* off2, const int32_t* len2,
+                         int32_t* out, int64_t dev_count, int32_t** d_scores);
 int  psa_packed_blocks_per_cu(int R);
 
 }  // namespace tsta

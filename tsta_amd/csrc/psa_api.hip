@@ -301,10 +301,32 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
                          int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
                          const int64_t* off2, const int32_t* len2, int32_t* out)
 {
+    if (!out && n_pairs > 0) return TSTA_ERR_INVALID_ARG;
+    return tsta::psa_score_batch_host(reinterpret_cast<Engine*>(eng), p, n_pairs, seqs, seqs_bytes, off1, len1, off2, len2, out, 0, nullptr);
+}
+
+}  // extern "C"
+
+namespace tsta {
+
+// tsta_psa_score_batch proper.  out (host) may be NULL when d_scores is given: the scores then stay on the device, in a
+// buffer of at least max(n_pairs, dev_count) int32 (tsta_psa_score_batch_multi gathers them with RCCL from there), and
+// the stream is synchronised either way.
+int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
+                         int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
+                         const int64_t* off2, const int32_t* len2, int32_t* out, int64_t dev_count, int32_t** d_scores)
+{
+    tsta_engine* eng = reinterpret_cast<tsta_engine*>(e);
     if (!eng || !p || n_pairs < 0 || seqs_bytes < 0) return TSTA_ERR_INVALID_ARG;
+    if (d_scores) {
+        *d_scores = nullptr;
+        int rc0 = e->check(hipSetDevice(e->device), "hipSetDevice");
+        if (rc0 != TSTA_OK) return rc0;
+        if ((rc0 = e->reserve(e->out_scores, (size_t)std::max<int64_t>(std::max(n_pairs, dev_count), 1) * sizeof(int32_t), "hipMalloc(scores)")) != TSTA_OK) return rc0;
+        *d_scores = reinterpret_cast<int32_t*>(e->out_scores.p);
+    }
     if (n_pairs == 0) return TSTA_OK;
-    if (!seqs || !off1 || !len1 || !off2 || !len2 || !out) return TSTA_ERR_INVALID_ARG;
-    Engine* e = reinterpret_cast<Engine*>(eng);
+    if (!seqs || !off1 || !len1 || !off2 || !len2 || (!out && !d_scores)) return TSTA_ERR_INVALID_ARG;
     int32_t max_len = 0;
     for (int64_t k = 0; k < n_pairs; ++k) {
         if (len1[k] < 0 || len2[k] < 0 || off1[k] < 0 || off2[k] < 0 ||
@@ -323,12 +345,15 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
         bool all_big = true;
         for (int64_t k = 0; k < n_pairs; ++k) all_big = all_big && (int64_t)len1[k] * len2[k] >= 200000000LL;
         if (all_big) {
+            std::vector<int32_t> tmp(out ? 0 : nb);
+            int32_t* res = out ? out : tmp.data();
             for (int64_t k = 0; k < n_pairs; ++k) {
                 const bool swap = len2[k] > len1[k];                                   // psa.c:194-199
                 const uint8_t* a = seqs + (swap ? off2[k] : off1[k]); const int n = swap ? len2[k] : len1[k];
                 const uint8_t* b = seqs + (swap ? off1[k] : off2[k]); const int m = swap ? len1[k] : len2[k];
-                if ((rc = tsta::psa_score_single_pair(e, p, a, n, b, m, &out[k])) != TSTA_OK) return rc;
+                if ((rc = tsta::psa_score_single_pair(e, p, a, n, b, m, &res[k])) != TSTA_OK) return rc;
             }
+            if (d_scores) return e->check(hipMemcpy(*d_scores, res, nb * sizeof(int32_t), hipMemcpyHostToDevice), "H2D scores");
             return TSTA_OK;
         }
     }
@@ -338,7 +363,7 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     const size_t meta_bytes = nb * (2 * sizeof(int64_t) + 2 * sizeof(int32_t));
     if ((rc = e->reserve(e->in_seqs, (size_t)seqs_bytes + 16, "hipMalloc(seqs)")) != TSTA_OK) return rc;
     if ((rc = e->reserve(e->in_meta, meta_bytes, "hipMalloc(meta)")) != TSTA_OK) return rc;
-    if ((rc = e->reserve(e->out_scores, nb * sizeof(int32_t), "hipMalloc(scores)")) != TSTA_OK) return rc;
+    if (!d_scores && (rc = e->reserve(e->out_scores, nb * sizeof(int32_t), "hipMalloc(scores)")) != TSTA_OK) return rc;
     char* m = reinterpret_cast<char*>(e->in_meta.p);
     int64_t* d_off1 = reinterpret_cast<int64_t*>(m);
     int64_t* d_off2 = d_off1 + nb;
@@ -352,9 +377,13 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
     rc = tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                   d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
-    if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
+    if (out && (rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
     return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
 }
+
+}  // namespace tsta
+
+extern "C" {
 
 
 int tsta_pack_2bit(const uint8_t* src, int64_t n, uint8_t* dst)

@@ -7,7 +7,10 @@
  * psa.c:512-516) followed by one "\n" as record separator.
  * With -A: ALL pairs — every record of -1 against every record of -2 (row-major: -2 varies fastest); each sequence is
  * stored once on the device, the pairs only carry offsets.  Lines then read "<i>\t<j>\tmaxsorce=%d" (1-based records).
- *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O] [-A] [-o alignments.txt]        env TSTA_DEVICE = GPU index */
+ * With -G <n>: the batch is sharded over n GPUs of this node (0 = all of them; tsta_psa_score_batch_multi /
+ * tsta_psa_align_batch_multi: contiguous shards balanced by DP cells, one engine per device; -R gathers the scores with
+ * RCCL over xGMI instead of one copy per device).  Output is identical whatever -G says.
+ *   TSTA_psa_batch -1 a.fa -2 b.fa [-M -X -E -O] [-A] [-G n [-R]] [-o alignments.txt]    env TSTA_DEVICE = GPU index (without -G) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,9 +23,9 @@ int main(int argc, char* argv[])
 {
     tsta_params prm = {2, -5, -2, -4};
     const char *input1 = NULL, *input2 = NULL, *output = NULL;
-    int all_pairs = 0;
+    int all_pairs = 0, n_gpus = -1, rccl = 0;
     int c;
-    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:o:A")) != -1) {
+    while ((c = getopt(argc, argv, "M:X:E:O:T:W:1:2:o:AG:R")) != -1) {
         switch (c) {
             case 'M': prm.M = atoi(optarg); break;
             case 'X': prm.X = atoi(optarg); break;
@@ -33,10 +36,12 @@ int main(int argc, char* argv[])
             case '2': input2 = optarg; break;
             case 'o': output = optarg; break;
             case 'A': all_pairs = 1; break;
-            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-o alignments.txt]\n"); return 2;
+            case 'G': n_gpus = atoi(optarg); break;
+            case 'R': rccl = 1; break;
+            default: fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-G gpus [-R]] [-o alignments.txt]\n"); return 2;
         }
     }
-    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-o alignments.txt]\n"); return 2; }
+    if (!input1 || !input2) { fprintf(stderr, "usage: TSTA_psa_batch -1 a.fa -2 b.fa [-M 2 -X -5 -E -2 -O -4] [-A] [-G gpus [-R]] [-o alignments.txt]\n"); return 2; }
     fasta_file* f1 = fasta_read(input1, 0);
     fasta_file* f2 = fasta_read(input2, 0);
     if (!all_pairs && f1->count != f2->count) { fprintf(stderr, "record counts differ: %zu vs %zu (use -A for all pairs)\n", f1->count, f2->count); return 1; }
@@ -62,14 +67,23 @@ int main(int argc, char* argv[])
     }
     const char* dev = getenv("TSTA_DEVICE");
     tsta_engine* eng = NULL;
-    int rc = tsta_engine_create(dev ? atoi(dev) : 0, &eng);
-    if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
+    tsta_multi* multi = NULL;
+    int rc;
+    if (n_gpus >= 0) {
+        rc = tsta_multi_create(NULL, n_gpus, &multi);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_multi_create(%d GPUs): %s\n", n_gpus, tsta_strerror(rc)); return 1; }
+        if (rccl) tsta_multi_set_option(multi, "gather", 1);
+    } else {
+        rc = tsta_engine_create(dev ? atoi(dev) : 0, &eng);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_engine_create: %s\n", tsta_strerror(rc)); return 1; }
+    }
     if (output) {
         tsta_alignment* al = (tsta_alignment*)calloc(n ? n : 1, sizeof(tsta_alignment));
         FILE* fo = fopen(output, "w");
         if (!fo) { fprintf(stderr, "cannot open %s\n", output); return 1; }
-        rc = tsta_psa_align_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, al);
-        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_align_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+        rc = multi ? tsta_psa_align_batch_multi(multi, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, al)
+                   : tsta_psa_align_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, al);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_align_batch: %s: %s\n", tsta_strerror(rc), multi ? tsta_multi_last_error(multi) : tsta_last_error(eng)); return 1; }
         for (size_t k = 0; k < n; k++) {
             fputs(">1\n", fo); fwrite(al[k].row_a, 1, (size_t)al[k].len, fo);
             fputs("\n>2\n", fo); fwrite(al[k].row_b, 1, (size_t)al[k].len, fo);
@@ -80,14 +94,16 @@ int main(int argc, char* argv[])
         tsta_alignments_free(al, (int64_t)n);
         free(al);
     } else {
-        rc = tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
-        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), tsta_last_error(eng)); return 1; }
+        rc = multi ? tsta_psa_score_batch_multi(multi, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out)
+                   : tsta_psa_score_batch(eng, &prm, (int64_t)n, seqs, (int64_t)total, off1, len1, off2, len2, out);
+        if (rc != TSTA_OK) { fprintf(stderr, "tsta_psa_score_batch: %s: %s\n", tsta_strerror(rc), multi ? tsta_multi_last_error(multi) : tsta_last_error(eng)); return 1; }
     }
     for (size_t k = 0; k < n; k++) {
         if (all_pairs) printf("%zu\t%zu\tmaxsorce=%d\n", k / n2 + 1, k % n2 + 1, out[k]);
         else           printf("maxsorce=%d\n", out[k]);
     }
     tsta_engine_destroy(eng);
+    tsta_multi_destroy(multi);
     fasta_free(f1); fasta_free(f2);
     free(seqs); free(off1); free(off2); free(len1); free(len2); free(out); free(start1); free(start2);
     return 0;
