@@ -35,8 +35,12 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86
 # K1p steady-state loop (R=32, pure-ACGT couple, block proven unable to raise the maximum): 532 VALU instructions per
 # 2 steps of 64 cells = 8 per cell pair (f-sub, v_perm lookup, diag-sub, 4 v_pk_max, g-sub) + 10 per step for the lane
 # hand-off.  The generic loop (any bytes, running max kept) is 11.3 per cell pair = 5.66 per cell.
-VALU_OPS_PER_CELL = 4.16
+VALU_OPS_PER_CELL = 4.16              # loop-body count (disassembly); superseded by the SQ_INSTS_VALU measurement in profiles/valu_psa_score.json
 VALU_OPS_PER_CELL_GENERIC = 5.66
+# what a SIMD sustains on this kernel's instruction mix (v_pk_max_u16 / v_perm_b32 / DPP at 4 cycles, v_sub_u32 at ~2.3,
+# alternating: 3.88): cycles per wave64 VALU instruction per SIMD at >= 2 waves per SIMD, tools/cell_microbench.hip,
+# profiles/r02a_cell_microbench.txt ("alternating sub / pk_max", "4 rows, clustered")
+MIX_CYCLES_PER_INSTR = 3.88
 
 
 def parse():
@@ -81,6 +85,15 @@ def make_shard(n_pairs, length, seed, device, related=None):
     return seqs, off1, ln, off2, ln.clone()
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    sys.stderr.write("[bench %6.1f s] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N>1) without a launcher: start torch.distributed.run as a CHILD process — before this
     process has made any GPU call; a process that has initialised the GPU must never exec another — let it print rank 0's
@@ -94,7 +107,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def run_reference(binary, threads, fa, fb, limit=120.0, tries=3):
+def run_reference(binary, threads, fa, fb, limit=30.0, tries=4):
     """One TSTA_psa_notrace process -> its stdout.  The reference's thread pool can deadlock (no join, unlocked shutdown
     flag: pthreadpool.c:96-117; seen here under oversubscription), so every run has a time limit and is retried."""
     last = None
@@ -106,6 +119,7 @@ def run_reference(binary, threads, fa, fb, limit=120.0, tries=3):
             last = RuntimeError("no maxsorce in output")
         except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as ex:
             last = ex
+            log("reference run failed or hung (%r); retrying" % (ex,))
     raise last
 
 
@@ -147,6 +161,7 @@ def verify_against_reference(seqs, off1, len1, off2, len2, scores, picks, cores)
         a = seqs[int(off1[k]):int(off1[k]) + int(len1[k])].cpu().numpy()
         b = seqs[int(off2[k]):int(off2[k]) + int(len2[k])].cpu().numpy()
         pairs.append((a, b))
+    log("verifying pairs %s against the reference" % (picks,))
     want, kind = reference_scores(pairs, cores)
     got = [int(scores[k]) for k in picks]
     assert got == want, "kernel scores differ from the %s on pairs %s: %s vs %s" % (kind, picks, got, want)
@@ -170,6 +185,7 @@ def cpu_throughput(length, cores, seed=777):
             files.append((fa, fb))
         for k in sorted({max(1, cores // 32), max(1, cores // 8), max(1, cores // 2)}):
             t_each = max(1, cores // k)
+            log("cpu_throughput: %d processes x -T %d" % (k, t_each))
             # calibrate on one lone run, then every worker (a shell loop: no Python between its runs) aligns `reps` pairs
             # back to back, about 8 s of work each
             c0 = time.perf_counter()
@@ -178,20 +194,21 @@ def cpu_throughput(length, cores, seed=777):
             except Exception:
                 continue
             one = max(1e-3, time.perf_counter() - c0)
-            reps = int(min(256, max(2, round(8.0 / one))))
             limit = max(5.0, 20.0 * one)            # a run that takes this long has deadlocked: it is killed and not counted
+            span = 8                                # every worker (a shell loop: no Python between its runs) aligns pairs back to back for ~8 s
             procs = []
             t0 = time.perf_counter()
             for w in range(k):
                 fa, fb = files[w % n_files]
-                sh = ("n=0; for i in $(seq %d); do timeout -k 2 %.0f %s -T %d -1 %s -2 %s > /dev/null && n=$((n+1)); done; echo $n"
-                      % (reps, limit, binary, t_each, fa, fb))
+                sh = ("end=$(( $(date +%%s) + %d )); n=0; t=0; while [ $(date +%%s) -lt $end ]; do t=$((t+1)); timeout -k 2 %.0f %s -T %d -1 %s -2 %s > /dev/null && n=$((n+1)); done; echo $n $t"
+                      % (span, limit, binary, t_each, fa, fb))
                 procs.append(subprocess.Popen(["sh", "-c", sh], stdout=subprocess.PIPE))
-            done = 0
+            done = tried = 0
             for pr in procs:
                 so, _ = pr.communicate()
                 try:
-                    done += int(so.decode().strip() or 0)
+                    a, b = so.decode().split()
+                    done += int(a); tried += int(b)
                 except ValueError:
                     pass
             dt = time.perf_counter() - t0
@@ -200,9 +217,9 @@ def cpu_throughput(length, cores, seed=777):
             v = float(done) * length * length / dt / 1e9
             if best is None or v > best["value"]:
                 best = {"value": v, "unit": "GCUPS", "cores": cores, "kind": "reference",
-                        "sample": "%d concurrent oracle/_ref/%s -T %d processes x %d pairs of %dx%d each, %.1f s; %d of %d runs "
+                        "sample": "%d concurrent oracle/_ref/%s -T %d workers aligning pairs of %dx%d back to back for %.1f s; %d of %d runs "
                                   "completed (the reference's thread pool can deadlock: such runs are killed at %.0f s)"
-                                  % (k, os.path.basename(binary), t_each, reps, length, length, dt, done, k * reps, limit)}
+                                  % (k, os.path.basename(binary), t_each, length, length, dt, done, tried, limit)}
     return best
 
 
@@ -285,6 +302,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     P, L = args.pairs_per_gpu, args.len
+    log("rank %d/%d: generating %d pairs of %d x %d" % (rank, world, P, L, L))
     eng = tsta_amd.Engine(local_rank)
     params = tsta_amd.Params()
     seqs, off1, len1, off2, len2 = make_shard(P, L, 1000 + rank, dev)
@@ -306,6 +324,7 @@ def main():
             gathered[0] = gather_scores(scores.cpu() if rehearsal else scores, P * world)
 
     torch.cuda.synchronize()
+    log("warmup + %d timed steps" % args.steps)
     with torch.cuda.stream(tstream):
         for _ in range(args.warmup):
             step()
@@ -337,6 +356,7 @@ def main():
     # the same shard once more down the generic path (any byte alphabet, running max kept in every block): what the
     # kernel does when neither of its two data-dependent shortcuts applies.  Results must be identical.
     generic_ms = None
+    log("timed region done: %.1f ms per step" % (dt / max(1, args.steps) * 1e3))
     if world == 1 and not args.no_generic:
         first = scores.clone()
         eng.set_option("psa_elide", 0); eng.set_option("psa_perm", 0)
@@ -369,10 +389,12 @@ def main():
     # running-max elision then applies to every band except those the high-scoring diagonal crosses
     related = None
     if world == 1 and not args.no_related:
+        log("related-pairs shard")
         del seqs
         torch.cuda.empty_cache()
         rseqs, roff1, rlen1, roff2, rlen2 = make_shard(P, L, 5000 + rank, dev, related=5.0)
-        rscores = torch.empty(P, dtype=torch.int32, device=dev)
+        rscores = torch.full((P,), -2 ** 31, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()                    # the shard is generated on torch's default stream, the kernel runs on tstream
         with torch.cuda.stream(tstream):
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for i in range(2):
@@ -401,6 +423,27 @@ def main():
                 tj = json.load(f)
             if tj.get("pairs_per_gpu") == P and tj.get("len") == L:
                 traffic = tj.get("hbm_bytes_per_launch")
+        # VALU roofline: instructions per cell MEASURED with SQ_INSTS_VALU on this workload (profiles/valu_psa_score.json, made
+        # by tools/collect_profiles.py from a rocprofv3 --pmc run of this script) when it matches, else the loop-body count
+        ops, ops_src, clk = VALU_OPS_PER_CELL, "loop body (disassembly)", 2.38e9
+        vp = os.path.join(ROOT, "profiles", "valu_psa_score.json")
+        if os.path.exists(vp):
+            with open(vp) as f:
+                vj = json.load(f)
+            if vj.get("pairs_per_gpu") == P and vj.get("len") == L:
+                ops, ops_src = vj["ops_per_cell"], "SQ_INSTS_VALU x 64 / cells (profiles/valu_psa_score.json)"
+                clk = (vj.get("shader_clock_GHz_from_GRBM_GUI_ACTIVE") or 2.38) * 1e9
+        lane_ops = float(P) * L * L * ops / (kern_ms * 1e-3)
+        n_simd = 256 * 4
+        cyc_per_instr = kern_ms * 1e-3 * clk / (float(P) * L * L * ops / 64.0 / n_simd)
+        valu = {"ops_per_cell": ops, "ops_per_cell_source": ops_src, "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
+                "unit": "T lane-ops/s", "frac": lane_ops / VALU_PEAK_LANEOPS,
+                "cycles_per_valu_instr_per_simd": cyc_per_instr, "mix_floor_cycles_per_instr": MIX_CYCLES_PER_INSTR,
+                "frac_of_measured_ceiling": MIX_CYCLES_PER_INSTR / cyc_per_instr, "shader_clock_hz": clk,
+                "note": "peak = data-sheet rate (one wave64 instruction per 2 cycles per SIMD), reached only by pure add/sub/logic "
+                        "streams; this kernel's mix sustains one per %.2f cycles in isolation (profiles/r02a_cell_microbench.txt), "
+                        "and SQ counters show every VALU instruction of it accounted one quad-cycle "
+                        "(SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU, profiles/valu_psa_score.json)" % MIX_CYCLES_PER_INSTR}
         out = {
             "metric": "GCUPS (DP cells/s) for batched 50kbp global affine-gap alignment",
             "value": cells_per_step * args.steps / dt / 1e9,
@@ -426,12 +469,7 @@ def main():
             # data-sheet VALU peak (one wave64 instruction per 2 cycles per SIMD, reached only by pure add/sub/logic streams)
             # and, next to it, the rate every stream containing max/min/perm/packed ops sustains on gfx950: one wave64
             # instruction per 4 cycles per SIMD (16 lanes/cycle; tools/cell_microbench.hip)
-            "valu_roofline": {"ops_per_cell": VALU_OPS_PER_CELL,
-                              "measured_issue_ceiling": 256 * 4 * 64 * 2.39e9 / 4.0 / 1e12,
-                              "frac_of_measured_ceiling": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / (256 * 4 * 64 * 2.39e9 / 4.0),
-                              "achieved": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / 1e12,
-                              "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
-                              "frac": float(P) * L * L * VALU_OPS_PER_CELL / (kern_ms * 1e-3) / VALU_PEAK_LANEOPS},
+            "valu_roofline": valu,
         }
         out["ranks_seen"] = len(set(uuids))
         out["device_uuids"] = uuids
@@ -446,6 +484,7 @@ def main():
                                    "note": "same shard, psa_elide=0 psa_perm=0: no data-dependent shortcut; identical scores"}
         if not args.no_cpu_baseline and world == 1:
             n_s = args.cpu_sample_pairs or min(256, max(4, int(round(16 * (50_000.0 / L) ** 2))))
+            log("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(L, n_s)
             thr = cpu_throughput(L, out["cpu_baseline"]["cores"])
             if thr is not None:

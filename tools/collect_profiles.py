@@ -53,6 +53,44 @@ if fe and wr:
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                     "--no-cpu-baseline --no-generic (separate passes)"}
     json.dump(t, open(os.path.join(out, "traffic_psa_score.json"), "w"), indent=1)
+# SQ counters of the headline kernel (VALU issue evidence): profiles/valu_psa_score.json, read by bench.py
+def sq(sub, kernel):
+    f = sorted(glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    acc, dur = {}, 0
+    for r in csv.DictReader(open(f[-1])) if f else []:
+        if kernel in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return acc, dur
+
+
+c1, dur1 = sq("prof_sq", "psa_score_packed")
+c2, _ = sq("prof_sq2", "psa_score_packed")
+if c1.get("SQ_INSTS_VALU"):
+    P, L = 8192, 50000
+    cells = float(P) * L * L
+    insts = c1["SQ_INSTS_VALU"]
+    n_simd = 256 * 4
+    clk = (c2.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) / (dur1 * 1e-9) if c2.get("GRBM_GUI_ACTIVE") else None     # GRBM sums over the 8 XCDs
+    v = {"kernel": "psa_score_packed_kernel<32,2>", "pairs_per_gpu": P, "len": L, "duration_ns": dur1, "counters": {**c2, **c1},
+         "valu_wave_instructions": insts, "ops_per_cell": insts * 64.0 / cells,
+         "valu_instr_per_simd": insts / n_simd,
+         "shader_clock_GHz_from_GRBM_GUI_ACTIVE": clk / 1e9 if clk else None,
+         "cycles_per_valu_instruction_per_simd": (clk * dur1 * 1e-9) / (insts / n_simd) if clk else None,
+         "SQ_ACTIVE_INST_VALU_over_SQ_INSTS_VALU_quadcycles": c1.get("SQ_ACTIVE_INST_VALU", 0.0) / insts,
+         "reading": "SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md, cycle constants): a ratio of 1.0 means every VALU "
+                    "instruction of this kernel holds its SIMD's vector pipe for 4 cycles; kernel cycles / VALU instructions per SIMD "
+                    "= cycles_per_valu_instruction_per_simd: the two waves of a SIMD together issue one VALU instruction every that "
+                    "many cycles, i.e. the SIMD's VALU issue is saturated when it is ~3.9-4.0 (tools/cell_microbench: the same mix "
+                    "alone sustains 3.88-4.0)",
+         "command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU "
+                    "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic "
+                    "--no-related --no-verify   (second pass: GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR "
+                    "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS)"}
+    json.dump(v, open(os.path.join(out, "valu_psa_score.json"), "w"), indent=1)
+for name in ("cell_microbench", "valu_microbench", "step_microbench"):
+    if os.path.exists(os.path.join(base, name + ".txt")):
+        shutil.copy(os.path.join(base, name + ".txt"), os.path.join(out, "%s_%s.txt" % (tag, name)))
 for f, name in (("bench_default.json", "bench_default"), ("bench_prof.json", "bench_under_rocprof"), ("configs.jsonl", "configs")):
     if os.path.exists(os.path.join(base, f)):
         shutil.copy(os.path.join(base, f), os.path.join(out, "%s_%s.%s" % (tag, name, f.split(".")[-1])))
