@@ -19,6 +19,10 @@ extern "C" {
 #endif
 
 typedef enum tsta_status {
+    /* > 0: the call SUCCEEDED and its outputs are valid, but the REFERENCE's own output on this input is not a function
+     * of the input and the scoring alone: it depends on -W / the SIMD width of the build (tsta_poa_fill / tsta_poa_align
+     * document the three cases).  tsta_last_warning() says which one was seen. */
+    TSTA_WARN_REFERENCE_UNDEFINED = 1,
     TSTA_OK = 0,
     TSTA_ERR_INVALID_ARG = -1,
     TSTA_ERR_NO_DEVICE = -2,      /* no HIP device / extension cannot run: there is NO CPU fallback */
@@ -41,6 +45,7 @@ typedef struct tsta_engine tsta_engine;
 
 const char* tsta_strerror(int status);
 const char* tsta_last_error(const tsta_engine* eng);       /* text of the last failing HIP call */
+const char* tsta_last_warning(const tsta_engine* eng);     /* text behind the last TSTA_WARN_* status ("" if none) */
 int  tsta_device_count(void);                              /* <0: tsta_status */
 int  tsta_engine_create(int device, tsta_engine** out);
 void tsta_engine_destroy(tsta_engine* eng);
@@ -63,9 +68,10 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream
  *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline
- *   "poa_skewed"       0 (default) | 1: POA fill with the lane-skewed band pipeline (experiment, slower; poa_fill_skewed.hip)
  *   "trace_persistent" 0 (default) | 1: single-launch trace fill with flag hand-off (experiment, slower; psa_trace.hip)
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
+ *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against
+ *                      (default 640 = AVX512 x -W 10; the TSTA_msa drop-in passes 64 x its -W); multiple of 16, 16 .. 1048576
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */
 int  tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value);
 
@@ -144,6 +150,18 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  *   lastscore              : int32 [n_nodes], H(r, n)  (the reference keeps it for sinks: c-t-simd.c:577-578)
  *   best_sink              : sink with the highest lastscore, ties -> lowest index (c-t-simd.c:737-750)
  * Domain: every node has < 42 predecessors (poa.h:109 / trace code space).
+ *
+ * What is computed is the plain int32 partial-order DP that the reference's saturating int8 machinery encodes (SURVEY
+ * appendix A.2), with the column rule for a literal 'N' in `seq` applied consistently: H(r,c) := H(r,c-1) for every
+ * node, trace codes by equality with that value (c-t-simd.c:461,481,485-506).  Returns TSTA_WARN_REFERENCE_UNDEFINED
+ * (results valid) in the three situations where the reference's own output depends on -W / SIMD width:
+ *   (1) `seq` contains a literal 'N': the reference applies the rule in its second pass only, its speculative first pass
+ *       (c-t-simd.c:357-404) does not (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over
+ *       -W 3/5/10/16/30; on the other 23 this library's output is byte-identical, tests/golden/msa_n_golden.json);
+ *   (2) the sequence spans more L-blocks than the graph, ceil(n/L) > ceil(n_nodes/L): the first-column branch at
+ *       c-t-simd.c:194 lacks the guard of :263 (L = option "poa_ref_block");
+ *   (3) two predecessor rows of one node lie further apart than the reference's saturating offset tracker can
+ *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct tsta_dag_csr {
     int32_t        n_nodes;

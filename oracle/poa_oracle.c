@@ -43,7 +43,17 @@ int32_t oracle_poa_fill(const oracle_dag* g, const uint8_t* seq, int32_t n, cons
         const uint8_t base = g->base[r];
         for (int32_t c = 1; c <= n; c++) {
             const int32_t s = (seq[c - 1] == base) ? M : X;
-            int32_t bestq = NEG_INF, jq = 0, beste = NEG_INF, je = 0, je_open = 0;
+            /* a literal 'N' in the sequence is indistinguishable from the reference's pad character (readseq,
+             * c-t-simd.c:46): the column's delta H(r,c)-H(r,c-1) is forced to 0 for EVERY node (`max = blendv(max,
+             * zero, SN)`, c-t-simd.c:461,481) and the trace codes are decided by equality with that forced value
+             * (:485-506: lowest j with Q_j == H, else lowest j with Ein_j == H, else F).  Everything downstream (F, Eagg
+             * of the successors, the signs of esource / fsource, :508-538) uses the forced H.  NOTE: the reference
+             * applies this in its second pass only; its speculative first pass (:357-404) does not, so its own output
+             * on inputs with a literal N depends on -W / the SIMD width; this is the rule applied
+             * consistently. */
+            const int is_n = (seq[c - 1] == 'N');
+            const int32_t h_forced = Hr[c - 1];
+            int32_t bestq = NEG_INF, jq = 0, beste = NEG_INF, je = 0, je_open = 0, jq_n = -1, je_n = -1;
             for (int32_t j = 0; j < np; j++) {
                 const int32_t* Hp = H + (size_t)pl[j] * W; const int32_t* Ep = Ea + (size_t)pl[j] * W;
                 const int32_t q = Hp[c - 1] + s;
@@ -51,15 +61,18 @@ int32_t oracle_poa_fill(const oracle_dag* g, const uint8_t* seq, int32_t n, cons
                 const int32_t eo = Hp[c] + OE, ex = Ep[c] + E;
                 const int32_t ein = max2(ex, eo);
                 if (ein > beste) { beste = ein; je = j; je_open = (ein == eo); }
+                if (is_n && jq_n < 0 && q == h_forced) jq_n = j;
+                if (is_n && je_n < 0 && ein == h_forced) je_n = j;
             }
             const int32_t f_open = Hr[c - 1] + OE;
             f = max2(f + E, f_open);
-            const int32_t h = max2(bestq, max2(beste, f));
+            const int32_t h = is_n ? h_forced : max2(bestq, max2(beste, f));
             Hr[c] = h; Er[c] = beste;
             const size_t o = (size_t)r * (size_t)n + (size_t)(c - 1);
             if (source) {                                               /* c-t-simd.c:485-506 */
                 int8_t code;
-                if (bestq == h)      code = (int8_t)((seq[c - 1] == base ? 42 : 84) + jq);
+                if (is_n)            code = jq_n >= 0 ? (int8_t)((seq[c - 1] == base ? 42 : 84) + jq_n) : (je_n >= 0 ? (int8_t)je_n : 126);
+                else if (bestq == h) code = (int8_t)((seq[c - 1] == base ? 42 : 84) + jq);
                 else if (beste == h) code = (int8_t)(0 + je);
                 else                 code = 126;
                 source[o] = code;

@@ -78,3 +78,54 @@ def test_msa_cli_on_gpu(tmp_path, idx):
     r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O",
                         str(sc["O"]), "-T", "4", "-i", input_path(c, tmp_path), "-o", out], capture_output=True, timeout=600)
     check(c, r, out)
+
+
+# ---- inputs with literal 'N' (tests/golden/msa_n_golden.json, made by make_msa_n_golden.py): on the cases where the
+# reference's own output does not depend on -W, the N-column rule applied consistently reproduces it byte for byte
+from tests.golden.make_msa_n_golden import n_case_seqs  # noqa: E402
+
+with open(os.path.join(util.GOLDEN_DIR, "msa_n_golden.json")) as _f:
+    N_GOLDEN = json.load(_f)
+N_INVARIANT = [g for g in N_GOLDEN if g["w_invariant"]]
+
+
+def test_n_golden_has_both_kinds():
+    assert len(N_INVARIANT) >= 20 and len(N_GOLDEN) - len(N_INVARIANT) >= 10     # the W-dependence is on file too
+
+
+@pytest.mark.parametrize("idx", range(len(N_INVARIANT)))
+def test_n_inputs_with_oracle_fill(oracle_driver, tmp_path, idx):
+    c = N_INVARIANT[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, n_case_seqs(c))
+    r = subprocess.run([oracle_driver, "2", "-5", "-2", "-4", fa, out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    data = open(out, "rb").read()
+    assert len(data) == c["size"] and hashlib.md5(data).hexdigest() == c["md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(N_INVARIANT)))
+def test_n_inputs_msa_cli_on_gpu(tmp_path, idx):
+    c = N_INVARIANT[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, n_case_seqs(c))
+    r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-T", "4", "-i", fa, "-o", out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    data = open(out, "rb").read()
+    assert len(data) == c["size"] and hashlib.md5(data).hexdigest() == c["md5"]
+    assert r.stderr.decode().count("warning:") == 1 and "literal 'N'" in r.stderr.decode()      # said once, not an error
+
+
+def test_sixth_distinct_character_in_a_column_is_an_error_not_a_crash(oracle_driver, tmp_path):
+    # the reference's mismatch ring holds 4 aligned nodes besides the column's own (poa.h:109): five distinct characters
+    # in one column are fine, a sixth would write past the ring there (undefined behaviour); here it is a reported error
+    left, right = bytes(util.random_dna(1, 40)), bytes(util.random_dna(2, 40))
+    for chars, ok in ((b"ACGTN", True), (b"ACGTNR", False)):
+        fa, out = tmp_path / ("in%d.fa" % len(chars)), tmp_path / "out.txt"
+        fa.write_bytes(b"".join(b">s%d\n" % i + left + bytes([ch]) + right + b"\n" for i, ch in enumerate(chars)))
+        r = subprocess.run([oracle_driver, "2", "-5", "-2", "-4", str(fa), str(out)], capture_output=True, timeout=60)
+        if ok:
+            assert r.returncode == 0, r.stderr
+        else:
+            assert r.returncode != 0 and b"sixth distinct character" in r.stderr

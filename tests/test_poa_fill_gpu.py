@@ -121,24 +121,83 @@ def test_on_device_walk_random_dags(eng):
         assert (got, end_col) == (want, want_end)
 
 
-def test_lane_skewed_fill_variant(eng):
-    # K4s (poa_fill_skewed.hip), an opt-in experiment: same trace arrays, lastscore, best sink and on-device walk as K4
-    # on every fixture (graphs outside its fast path silently run K4) and on sparse random DAGs that stay inside it
+def sprinkle_n(seq, seed, positions=(), count=0):
+    seq = seq.copy()
+    for c in positions:
+        if 0 <= c < len(seq):
+            seq[c] = ord("N")
+    if count and len(seq):
+        idx = (util.splitmix64(seed, count) % np.uint64(len(seq))).astype(np.int64)
+        seq[idx] = ord("N")
+    return seq
+
+
+@pytest.mark.parametrize("cols", [2, 4])
+def test_literal_n_columns_vs_oracle(eng, cols):
+    # a literal 'N' in the sequence forces H(r,c) := H(r,c-1) for every node, trace codes by equality (c-t-simd.c:461,481,
+    # 485-506): first / last column, runs of N, several N per tile and per lane, tiles without N next to tiles with N,
+    # nodes whose base is 'N'; every trace byte, lastscore and the best sink against the oracle; the call reports
+    # TSTA_WARN_REFERENCE_UNDEFINED (the reference's own output on such input depends on -W)
     try:
-        eng.set_option("poa_skewed", 1)
-        for path in FIXTURES:
-            z, sc = load(path)
-            best, last, src, es, fs = eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"],
-                                                   tsta_amd.Params(**sc))
-            check_against_fixture(z, best, last, src, es, fs)
-            steps, end_col, _ = eng.poa_align(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"], tsta_amd.Params(**sc))
-            want_steps, want_end = util.poa_walk(z["pred_off"], z["pred"], z["is_sink"], last, src, es, fs)
-            assert end_col == want_end
-            assert [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps] == want_steps
-        for seed, V, extra, n in [(11, 300, 2, 500), (12, 900, 3, 1300), (13, 130, 2, 64), (14, 65, 1, 1)]:
-            pred_off, pred, base, is_sink, seq = random_dag(seed, V, extra, n)
-            got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
-            want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
-            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
+        eng.set_option("poa_cols", cols)
+        cases = [(21, 120, 3, 300, (0, 1, 2, 299, 150, 151, 152, 153), 0), (22, 400, 6, 1000, (127, 128, 129, 255, 256, 511, 512, 999), 12),
+                 (23, 70, 20, 129, (), 40), (24, 900, 4, 2000, (5,), 0), (25, 33, 2, 64, tuple(range(0, 64, 3)), 0), (26, 10, 2, 7, (6,), 0),
+                 (27, 200, 5, 513, tuple(range(100, 140)), 5)]
+        for seed, V, mp, n, pos, cnt in cases:
+            pred_off, pred, base, is_sink, seq = random_dag(seed, V, mp, n)
+            seq = sprinkle_n(seq, seed, pos, cnt)
+            base = base.copy(); base[::17] = ord("N")
+            for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0)):
+                got = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc))
+                assert eng.last_status == 1 and "literal 'N'" in eng.last_warning()
+                want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq, **sc)
+                assert got[0] == want[0], (seed, sc)
+                assert np.array_equal(got[1], want[1]), (seed, sc)
+                for name, g, w in zip(("source", "esource", "fsource"), got[2:], want[2:]):
+                    bad = np.argwhere(g != w)
+                    assert len(bad) == 0, (seed, sc, name, bad[:5].tolist(), g[tuple(bad[0])], w[tuple(bad[0])])
+            # the on-device walk over those arrays
+            best, last, src, es, fs = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+            want_steps, want_end = util.poa_walk(pred_off, pred, is_sink, last, src, es, fs)
+            steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
+            assert eng.last_status == 1
+            assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
     finally:
-        eng.set_option("poa_skewed", 0)
+        eng.set_option("poa_cols", 0)
+
+
+def test_reference_undefined_warnings(eng):
+    # inside the reference's domain (a dump of the reference itself): status 0, no warning
+    z, sc = load(FIXTURES[0])
+    eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"], tsta_amd.Params(**sc), want_trace=False)
+    assert eng.last_status == 0 and eng.last_warning() == ""
+    # (2) the sequence spans more L-blocks than the graph (c-t-simd.c:194 vs :263): L = option poa_ref_block
+    V = 600
+    chain_off = np.arange(V + 1, dtype=np.int32); chain_off[1:] -= 1; chain_off[0] = 0
+    chain_pred = np.arange(V - 1, dtype=np.int32)
+    cbase = util.random_dna(32, V); csink = np.zeros(V, np.uint8); csink[-1] = 1
+    seq = util.random_dna(34, 700)
+    eng.poa_fill(chain_off, chain_pred, cbase, csink, seq, want_trace=False)
+    assert eng.last_status == 1 and "spans more blocks" in eng.last_warning()
+    eng.set_option("poa_ref_block", 1024)
+    eng.poa_fill(chain_off, chain_pred, cbase, csink, seq, want_trace=False)
+    assert eng.last_status == 0
+    eng.set_option("poa_ref_block", 640)
+    # (3) two predecessor rows of one node far apart: a chain that spells the sequence and a chain of a base the sequence
+    # never has, joined in a final node
+    n = 200
+    seq = util.random_dna(33, n); seq[seq == ord("T")] = ord("A")
+    V = 2 * n + 1
+    base = np.concatenate([seq, np.full(n, ord("T"), np.uint8), [ord("A")]]).astype(np.uint8)
+    pred_off, pred = [0], []
+    for v in range(V):
+        if v == 2 * n:
+            pred += [n - 1, 2 * n - 1]
+        elif v not in (0, n):
+            pred += [v - 1]
+        pred_off.append(len(pred))
+    is_sink = np.zeros(V, np.uint8); is_sink[-1] = 1
+    got = eng.poa_fill(np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq)
+    assert eng.last_status == 1 and "apart" in eng.last_warning()
+    want = util.oracle_poa_fill(np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))

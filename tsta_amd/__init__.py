@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit", "tsta_engine_release_workspaces",
     "tsta_multi_create", "tsta_multi_destroy", "tsta_multi_device_count", "tsta_multi_engine", "tsta_multi_last_error",
     "tsta_multi_set_option", "tsta_shard_bounds", "tsta_psa_score_batch_multi", "tsta_psa_align_batch_multi",
-    "tsta_build_info", "tsta_device_uuid",
+    "tsta_build_info", "tsta_device_uuid", "tsta_last_warning",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         L.tsta_strerror.restype = C.c_char_p; L.tsta_strerror.argtypes = [C.c_int]
         L.tsta_last_error.restype = C.c_char_p; L.tsta_last_error.argtypes = [vp]
+        L.tsta_last_warning.restype = C.c_char_p; L.tsta_last_warning.argtypes = [vp]
         L.tsta_device_count.restype = C.c_int; L.tsta_device_count.argtypes = []
         L.tsta_engine_create.restype = C.c_int; L.tsta_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.tsta_engine_destroy.restype = None; L.tsta_engine_destroy.argtypes = [vp]
@@ -274,9 +275,15 @@ class Engine:
         self._check(lib().tsta_engine_set_option(self._h, key.encode(), int(value)), "tsta_engine_set_option(%s)" % key)
 
     def _check(self, rc, what):
-        if rc != 0:
+        # rc > 0 = TSTA_WARN_*: the call succeeded (see last_status / last_warning()); rc < 0 = error
+        self.last_status = int(rc)
+        if rc < 0:
             raise TstaError("%s: %s (%s)" % (what, lib().tsta_strerror(rc).decode(),
                                              lib().tsta_last_error(self._h).decode()))
+
+    def last_warning(self):
+        """Text behind the last positive (TSTA_WARN_*) status of this engine."""
+        return lib().tsta_last_warning(self._h).decode()
 
     # ---- PSA score-only batch (TSTA_psa_notrace fill for many pairs) ------------------------------
     def psa_score_batch(self, pairs, params=None):

@@ -54,6 +54,7 @@ const char* tsta_strerror(int status)
 {
     switch (status) {
         case TSTA_OK: return "ok";
+        case TSTA_WARN_REFERENCE_UNDEFINED: return "ok, but the reference's own output on this input depends on -W / SIMD width";
         case TSTA_ERR_INVALID_ARG: return "invalid argument";
         case TSTA_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
         case TSTA_ERR_HIP: return "HIP runtime error";
@@ -87,6 +88,11 @@ int tsta_device_uuid(int device, char* out33)
     return TSTA_OK;
 }
 
+const char* tsta_last_warning(const tsta_engine* eng)
+{
+    return eng ? reinterpret_cast<const Engine*>(eng)->warn : "";
+}
+
 int tsta_device_count(void)
 {
     int n = 0;
@@ -110,7 +116,6 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (const char* v = getenv("TSTA_TRACE_PERSISTENT")) e->opt_trace_persistent = atoi(v) != 0;
     if (const char* v = getenv("TSTA_TRACE_STREAMS")) e->opt_trace_streams = atoi(v);
     if (const char* v = getenv("TSTA_PSA_BANDS")) e->opt_psa_bands = atoi(v);
-    if (const char* v = getenv("TSTA_POA_SKEWED")) e->opt_poa_skewed = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
@@ -208,8 +213,8 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_bands") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_bands = (int)v; return TSTA_OK; }
     if (!strcmp(key, "psa_ffree") && (v == 0 || v == 1)) { e->opt_psa_ffree = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
-    if (!strcmp(key, "poa_skewed") && (v == 0 || v == 1)) { e->opt_poa_skewed = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
+    if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;
 }

@@ -38,6 +38,7 @@ __global__ void poa_init_kernel(PoaArgs A)
 {
     // virtual init row (c-t-simd.c:82-94,174-188): H = 0, O+c*E ; no vertical gap state
     int* Hi = A.Hrow; int* Ei = A.Erow;                       // slot 0
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.best[8] = 0;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= A.n; c += gridDim.x * blockDim.x) {
         Hi[c + 3] = c == 0 ? 0 : A.O + c * A.E;
         Ei[c] = kNeg;
@@ -65,6 +66,30 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
 #pragma unroll
     for (int k = 0; k < KC; ++k) sch[k] = (c0 + k < n) ? (int)A.seq[c0 + k] : -1;
 
+    // A literal 'N' in the sequence (c-t-simd.c:46,349,461,481): the column's H is FORCED to the H of
+    // the column on its left, for every node.  That breaks the one-value max-plus scan of F below (the forced column needs
+    // H, not only Fbar), so a tile with N columns resolves its rows segment by segment (fill_row_with_n): the ordered list of
+    // the tile's N columns (tile-relative, 0 .. kCW-1) is built once per tile.  Tiles without N (the normal case) never see it.
+    __shared__ short n_pos[kCW];
+    int n_cnt = 0;
+    {
+        int before = 0, mine = 0;
+        unsigned long long any = 0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const unsigned long long mk = __ballot(sch[k] == 'N');
+            any |= mk;
+            before += __popcll(mk & ((1ull << lane) - 1ull));
+            n_cnt += __popcll(mk);
+        }
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (sch[k] == 'N') { n_pos[before + mine] = (short)(lane * KC + k); ++mine; }
+            __syncthreads();
+        }
+    }
+
     // per-row side data of this tile, row r0+i in lane i
     int xin_l = 0, flag_l = 1, edge_l = 0;
     int slot_l = 0;
@@ -84,7 +109,7 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
     }
     // scan weights: distance (in lanes) to the source lane of the two cross-row DPP broadcasts
     const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
-    int cout_l = 0, fout_l = 0;
+    int cout_l = 0, fout_l = 0, spread_l = 0;
 
     int hs_prev[KC], es_prev[KC], prev_r = -2, h0_prev = 0;
 #pragma unroll
@@ -128,10 +153,10 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
         }
         const int npp = is_src ? 1 : np;
         bool synced = false;
-        for (int j = 0; j < npp; ++j) {
+        // H(p, c0 .. c0+KC) and Eagg(p, c0+1 .. c0+KC) of predecessor j of this row
+        auto load_pred = [&](int j, int (&hv)[KC + 1], int (&ev)[KC]) {
             const int p = is_src ? A.V : ((j == 0) ? pfirst : A.pred[p0 + j]);
             const int ps = is_src ? 0 : ((j == 0) ? pfslot : A.pred_slot[p0 + j]);
-            int hv[KC + 1], ev[KC];
             if (p == prev_r) {
                 // predecessor = the row this wave has just finished: registers + one lane shift, no memory
                 const int edge = (q == 0) ? h0_prev : __builtin_amdgcn_readlane(edge_l, i - 1);
@@ -166,6 +191,13 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                     ev[0] = ea.x; ev[1] = ea.y;
                 }
             }
+        };
+        int hmx[KC], hmn[KC];                                // nodes with several predecessors: how far apart their rows lie
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { hmx[k] = kNeg; hmn[k] = -kNeg; }
+        for (int j = 0; j < npp; ++j) {
+            int hv[KC + 1], ev[KC];
+            load_pred(j, hv, ev);
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const int qv = hv[k] + sc[k];                              // diagonal from H(p, c-1)
@@ -173,8 +205,19 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
                 const int eo = hv[k + 1] + OE, ex = ev[k] + E;             // c-t-simd.c:524-528
                 const int ein = max(ex, eo);
                 if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
+                if (npp > 1) { hmx[k] = max(hmx[k], hv[k + 1]); hmn[k] = min(hmn[k], hv[k + 1]); }
             }
         }
+        if (npp > 1) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
+        }
+        int hs[KC], es[KC], fl[KC];
+        bool opn[KC + 1];
+        opn[0] = false;
+        int xout;
+        int jqn[KC], jen[KC];                                // N columns: lowest j with Q_j == H / Ein_j == H (-1: none)
+        if (n_cnt == 0) {
         // ---- F: local pass with no carry-in, then a max-plus inclusive scan over the 64 lanes
         int fbar = kNeg;
 #pragma unroll
@@ -193,12 +236,9 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
         v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
         const int prev = dpp_shr1(kNeg, v);
         const int xin = max(prev, xin_row + lane * aK);      // Fbar entering this lane's first column
-        const int xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);   // ... entering the next chunk
+        xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);   // ... entering the next chunk
         // ---- fix-up pass with the true carry: final H, Eagg, trace codes
         fbar = xin;
-        int hs[KC], es[KC], fl[KC];
-        bool opn[KC + 1];
-        opn[0] = false;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int f = fbar + E;
@@ -207,6 +247,94 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
             const int g = h + O;
             opn[k + 1] = (g >= f);                           // F(c+1) == H(c)+O+E  <=>  H(c)+O >= F(c)
             fbar = max(f, g);
+        }
+        } else {
+        // ---- tile with literal 'N' columns: the row is resolved segment by segment.  Round t finalises the columns
+        // [S, Nn) between two N columns with the scan above (Fbar injected at column S instead of at the chunk's left
+        // edge), then the N column Nn itself: H := H(Nn-1), F and the open flag from that forced H.
+        const int row_edge = (q == 0) ? h0 : __builtin_amdgcn_readlane(edge_l, i);    // H(r, cbase)
+        int S = 0, FbS = xin_row;
+        int fa[KC];                                          // Fbar after each of the lane's columns (final once its segment is done)
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { hs[k] = 0; fl[k] = 0; fa[k] = kNeg; es[k] = be[k]; opn[k + 1] = false; }
+        int v = kNeg;
+        for (int t = 0; t <= n_cnt; ++t) {
+            const int Nn = (t < n_cnt) ? __builtin_amdgcn_readfirstlane((int)n_pos[t]) : kCW;
+            if (Nn > S) {
+                int fbar = kNeg;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int cc = lane * KC + k;
+                    if (cc == S) fbar = FbS;
+                    if (cc >= S && cc < Nn) {
+                        const int f = fbar + E;
+                        const int h = max(max(bq[k], be[k]), f);
+                        fbar = max(f, h + O);
+                    }
+                }
+                v = fbar;                                     // lanes left of S carry kNeg; lanes right of Nn are redone later
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false) + aK);
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false) + 2 * aK);
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false) + 4 * aK);
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false) + 8 * aK);
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false) + w15);
+                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
+                fbar = dpp_shr1(kNeg, v);
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int cc = lane * KC + k;
+                    if (cc == S) fbar = FbS;
+                    if (cc >= S && cc < Nn) {
+                        const int f = fbar + E;
+                        const int h = max(max(bq[k], be[k]), f);
+                        hs[k] = h; fl[k] = f;
+                        const int g = h + O;
+                        opn[k + 1] = (g >= f);
+                        fbar = max(f, g);
+                        fa[k] = fbar;
+                    }
+                }
+            }
+            if (Nn < kCW) {
+                // the N column: H(Nn) := H(Nn-1) (c-t-simd.c:461,481); F(Nn) = Fbar(Nn-1) + E; wave-uniform scalars
+                const int lN = Nn / KC, kN = Nn % KC;
+                int hb, fb;
+                {
+                    int hsel = hs[KC - 1], fsel = fa[KC - 1];   // value of column Nn-1: column kN-1 of lane lN, or the last column of lane lN-1
+#pragma unroll
+                    for (int k = 0; k + 1 < KC; ++k) if (kN == k + 1) { hsel = hs[k]; fsel = fa[k]; }
+                    const int src_lane = kN > 0 ? lN : max(lN - 1, 0);
+                    hb = Nn == 0 ? row_edge : __builtin_amdgcn_readlane(hsel, src_lane);
+                    fb = Nn == S ? FbS : __builtin_amdgcn_readlane(fsel, src_lane);
+                }
+                const int f = fb + E, g = hb + O;
+                const int fbn = max(f, g);
+                if (lane == lN) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) if (k == kN) { hs[k] = hb; fl[k] = f; opn[k + 1] = (g >= f); fa[k] = fbn; }
+                }
+                S = Nn + 1; FbS = fbn;
+            }
+        }
+        // Fbar entering the next chunk: after the last column (an N column, or the end of the last segment)
+        {
+            int fsel = fa[KC - 1];
+            xout = __builtin_amdgcn_readlane(fsel, 63);
+        }
+        // trace codes of the N columns are decided by EQUALITY with the forced H (c-t-simd.c:485-506): second look at the predecessors
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { jqn[k] = -1; jen[k] = -1; }
+        for (int j = 0; j < npp; ++j) {
+            int hv[KC + 1], ev[KC];
+            load_pred(j, hv, ev);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int qv = hv[k] + sc[k];
+                const int ein = max(ev[k] + E, hv[k + 1] + OE);
+                if (jqn[k] < 0 && qv == hs[k]) jqn[k] = j;
+                if (jen[k] < 0 && ein == hs[k]) jen[k] = j;
+            }
+        }
         }
         // open flag of the lane's first column comes from the lane on the left (or the chunk/row boundary)
         const int opn_last = opn[KC] ? 1 : 0;
@@ -220,7 +348,8 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
             for (int k = 0; k < KC; ++k) {
                 const int h = hs[k], f = fl[k];
                 int code;                                    // match > mismatch > E > F (c-t-simd.c:485-506)
-                if (bq[k] == h) code = (mt[k] ? 42 : 84) + jq[k];
+                if (n_cnt != 0 && sch[k] == 'N') code = jqn[k] >= 0 ? (mt[k] ? 42 : 84) + jqn[k] : (jen[k] >= 0 ? jen[k] : 126);
+                else if (bq[k] == h) code = (mt[k] ? 42 : 84) + jq[k];
                 else if (be[k] == h) code = je[k] & 63;
                 else code = 126;
                 int ecode = ((je[k] & 64) ? 43 : 1) + (je[k] & 63);        // c-t-simd.c:530-538
@@ -270,6 +399,11 @@ __global__ __launch_bounds__(64) void poa_tile_kernel(PoaArgs A)
         A.carry[(size_t)(r0 + lane) * ncar + q + 1] = cout_l;
         A.cflag[(size_t)(r0 + lane) * ncar + q + 1] = (uint8_t)fout_l;
     }
+    if (__ballot(spread_l > 0)) {                            // (tiles of backbone-only rows never get here)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) spread_l = max(spread_l, __shfl_xor(spread_l, off, 64));
+        if (lane == 0) atomicMax(A.best + 8, spread_l);
+    }
 }
 
 // best sink: max lastscore, ties -> lowest index (c-t-simd.c:737-750)
@@ -298,7 +432,6 @@ struct PoaWalkArgs {
     int V, n;
     const int* pred_off; const int* pred; const uint8_t* is_sink;
     const int8_t* source; const int8_t* esource; const int8_t* fsource; int64_t tpitch;
-    int skew;                            // 1: node r's column c is byte c + (r & 63) of its row (lane-skewed fill)
     const int* lastscore;
     tsta_poa_step* steps;                // out, capacity V + n + 2
     int* out;                            // out[0] = number of steps, out[1] = end column, out[2] = start node
@@ -324,7 +457,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 
     while (num1 != -1 && num2 != -1) {
         // stage the window whose lower-right region holds (num1, num2)
-        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - (A.skew ? 32 : 48)) & ~15);   // skewed rows: 49 usable columns per piece
+        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
         {
             const int rr = rw0 + lane;
             uint4 t[3][4];
@@ -336,8 +469,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    // (skewed rows: the 64 bytes staged for row rr start at the aligned byte at or below its column cw0)
-                    const int64_t col = ((cw0 + (A.skew ? (rr & 63) : 0)) & ~15) + 16 * x;
+                    const int64_t col = cw0 + 16 * x;
                     t[a][x] = (rr < A.V && col < A.tpitch) ? *reinterpret_cast<const uint4*>(base + (size_t)rr * A.tpitch + col)
                                                             : make_uint4(0, 0, 0, 0);
                 }
@@ -359,16 +491,15 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         __syncthreads();
         const int8_t* wb = reinterpret_cast<const int8_t*>(win);
         auto rd = [&](int a, int row, int col) -> int {      // trace byte of array a at (row, col)
-            const int sk = A.skew ? (row & 63) : 0;
-            const int off = col + sk - ((cw0 + sk) & ~15);     // byte of the staged 64-byte piece of this row
+            const int off = col - cw0;                         // byte of the staged 64-byte piece of this row
             if (row >= rw0 && row < rw0 + 64 && off >= 0 && off < 64)
                 return wb[(a * 64 + (row - rw0)) * 64 + off];
             const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
-            return base[(size_t)row * A.tpitch + col + sk];
+            return base[(size_t)row * A.tpitch + col];
         };
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
-            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + (A.skew ? 49 : 64)) break;   // restage
+            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + 64) break;   // restage
             if (forced < 0) {
                 // ---- run of match / mismatch cells along the backbone, taken at once: lane l probes cell
                 // (num1 - l, num2 - l); the run continues while the cell is a diagonal move (:786-860, :861-956) whose
@@ -377,8 +508,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 bool have = false, okc = false;
                 int code_l = 0;
                 if (r >= rw0 && c >= 0) {
-                    const int sk = A.skew ? (r & 63) : 0;
-                    const int off = c + sk - ((cw0 + sk) & ~15);
+                    const int off = c - cw0;
                     if (off >= 0 && off < 64) {
                         have = true;
                         code_l = wb[(0 * 64 + (r - rw0)) * 64 + off];
@@ -448,17 +578,31 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 
 namespace tsta {
 
-// plain [V][npl] copies of the three skewed trace arrays (tsta_poa_fill hands the arrays to the host)
-__global__ void poa_deskew_kernel(const int8_t* src, int64_t tpitch, int V, int n, int8_t* dst, int64_t npl, int r0)
-{
-    const int r = r0 + blockIdx.y, a = blockIdx.z;
-    const int8_t* sr = src + ((size_t)a * V + r) * tpitch + (r & 63);
-    int8_t* dr = dst + ((size_t)a * V + r) * npl;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) dr[c] = sr[c];
-}
-
 void launch_poa_init(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (A.n + 256) / 256)), dim3(256), 0, s, A); }
 void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A); }
+
+// The three situations in which the reference's own output depends on -W / SIMD width (include/tsta_engine.h,
+// tsta_poa_fill): sets e->warn and returns TSTA_WARN_REFERENCE_UNDEFINED, else TSTA_OK.  `spread` = largest distance seen
+// on the device between two predecessor rows of one node.
+static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread)
+{
+    e->warn[0] = 0;
+    const int64_t L = e->opt_poa_ref_block;
+    const int m = std::max(std::abs(p->M), std::abs(p->X)) + std::abs(p->O) + std::abs(p->E);
+    const int limit = std::max(64, 354 - 2 * m);            // tracker range 100+127+127 (c-t-simd.c:196-261) minus what one row can add
+    const void* nptr = memchr(seq, 'N', (size_t)n);
+    if (nptr)
+        snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
+                 "in the second pass only (c-t-simd.c:357-404 vs :461), so its own output for such input depends on -W; this result applies "
+                 "the rule consistently", (long long)(static_cast<const uint8_t*>(nptr) - seq));
+    else if (((int64_t)n + L - 1) / L > ((int64_t)V + L - 1) / L)
+        snprintf(e->warn, sizeof(e->warn), "the sequence (%d) spans more blocks of L=%lld than the graph (%d nodes): the reference's first-column "
+                 "branch (c-t-simd.c:194, unguarded unlike :263) makes its own output depend on -W here", n, (long long)L, V);
+    else if (spread > limit)
+        snprintf(e->warn, sizeof(e->warn), "two predecessor rows of one node lie %d apart (limit %d): beyond the reference's saturating offset "
+                 "tracker (c-t-simd.c:196-261,370-404), its own output may deviate from the DP computed here", spread, limit);
+    return e->warn[0] ? TSTA_WARN_REFERENCE_UNDEFINED : TSTA_OK;
+}
 
 // Validation, uploads, workspace and the fill launches; leaves everything on the device.
 static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
@@ -475,13 +619,6 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
-    A.skew = 0;
-    if (e->opt_poa_skewed != 0) {                            // K4s: lane-skewed band pipeline, when the graph fits its fast path
-        bool used = false;
-        if ((rc = poa_run_skewed(e, p, dag, seq, n, want_trace, A, &used)) != TSTA_OK) return rc;
-        if (used) return TSTA_OK;
-        A.skew = 0;
-    }
 
     // 4 columns per lane (256-column tiles) are cheaper per cell; 2 per lane put twice as many tiles in flight,
     // which wins while the sequence is short enough that the tile wavefront is the limit
@@ -595,29 +732,18 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
     e->timing_end(s);
-    int h_best = -1;
-    if ((rc = e->check(hipMemcpyAsync(&h_best, A.best, 4, hipMemcpyDeviceToHost, s), "D2H best"))) return rc;
+    int h_res[9] = {-1, 0, 0, 0, 0, 0, 0, 0, 0};
+    if ((rc = e->check(hipMemcpyAsync(h_res, A.best, sizeof(h_res), hipMemcpyDeviceToHost, s), "D2H best"))) return rc;
     if (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) return rc;
-    if (want_trace && A.skew) {
-        const int64_t npl = ((int64_t)n + 15) / 16 * 16;
-        if ((rc = e->reserve(e->scratch2, 3 * (size_t)V * npl + 64, "hipMalloc(plain trace)"))) return rc;
-        int8_t* pl = reinterpret_cast<int8_t*>(e->scratch2.p);
-        for (int r0 = 0; r0 < V; r0 += 65535)
-            hipLaunchKernelGGL(poa_deskew_kernel, dim3(std::min(16, (n + 255) / 256), (unsigned)std::min(65535, V - r0), 3), dim3(256), 0, s,
-                               A.source, A.tpitch, V, n, pl, npl, r0);
-        if ((rc = e->check(hipMemcpy2DAsync(source, n, pl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
-            (rc = e->check(hipMemcpy2DAsync(esource, n, pl + (size_t)V * npl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
-            (rc = e->check(hipMemcpy2DAsync(fsource, n, pl + 2 * (size_t)V * npl, npl, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
-            return rc;
-    } else if (want_trace) {
+    if (want_trace) {
         if ((rc = e->check(hipMemcpy2DAsync(source, n, A.source, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H source")) ||
             (rc = e->check(hipMemcpy2DAsync(esource, n, A.esource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H esource")) ||
             (rc = e->check(hipMemcpy2DAsync(fsource, n, A.fsource, A.tpitch, n, V, hipMemcpyDeviceToHost, s), "D2H fsource")))
             return rc;
     }
     if ((rc = e->check(hipStreamSynchronize(s), "poa_fill sync"))) return rc;
-    if (best_sink) *best_sink = h_best;
-    return TSTA_OK;
+    if (best_sink) *best_sink = h_res[0];
+    return poa_reference_warning(e, p, V, seq, n, h_res[8]);
 }
 
 extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
@@ -638,7 +764,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)"))) return rc;
     PoaWalkArgs Wk;
     Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink;
-    Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch; Wk.skew = A.skew;
+    Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch;
     Wk.lastscore = A.lastscore;
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
     Wk.out = A.best + 4;
@@ -646,7 +772,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
-    int h_out[4] = {0, 0, 0, 0};
+    int h_out[5] = {0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
     if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
@@ -657,5 +783,5 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     if (!out) return TSTA_ERR_OOM;
     if (ns && (rc = e->check(hipMemcpy(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost), "D2H steps"))) { free(out); return rc; }
     *steps = out; *n_steps = ns; *end_col = h_out[1];
-    return TSTA_OK;
+    return poa_reference_warning(e, p, V, seq, n, h_out[4]);
 }

@@ -1,5 +1,4 @@
-// poa_types.h — arguments shared by the POA fill kernels (poa_fill.hip: tile wavefront; poa_fill_skewed.hip: lane-skewed
-// band pipeline), the best-sink reduction and the walker.
+// poa_types.h — arguments of the POA fill kernel (poa_fill.hip: tile wavefront), the best-sink reduction and the walker.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,19 +29,12 @@ struct PoaArgs {
     int kc;                              // columns per lane of this run (2 or 4)
     int8_t* source; int8_t* esource; int8_t* fsource; int64_t tpitch;   // [V][tpitch] device layout (tpitch mult. of 8)
     int* lastscore;                      // [V]
-    int* best;                           // [0] = best sink
+    int* best;                           // [0] = best sink; [4..7] walker results; [8] = largest spread seen between two predecessor rows of a node
     int M, X, E, O;
-    int skew;                            // 1: row r's column c lives at index c + (r & 63) of Hrow/Erow/trace rows (lane-skewed fill)
 };
 
 
 void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
 void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
-
-// poa_fill_skewed.hip: the lane-skewed fill.  Returns TSTA_OK and sets *used = true when it ran (A is then complete and
-// the trace arrays / H rows are in the SKEWED layout, A.skew = 1); *used = false when the graph does not fit its
-// fast path (in-degree > 4 or too many non-backbone predecessors in one 64-node band) and the tile kernel must run.
-int poa_run_skewed(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
-                   bool want_trace, PoaArgs& A, bool* used);
 
 }  // namespace tsta

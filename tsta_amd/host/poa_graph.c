@@ -163,7 +163,9 @@ static pg_step* walk_arrays(const pg_graph* g, int len_b, const int32_t* pred_of
 }
 
 /* The graph surgery of node_fuse (c-t-simd.c:659-977) driven by the recorded walk. */
-static void apply_path(pg_graph* g, const char* b, int num, const pg_step* steps, int64_t n_steps, int end_col)
+/* returns 0, or PG_ERR_RING_FULL when a column would need a sixth distinct character (the reference's mismatch_node[4],
+ * poa.h:109, overflows there: undefined behaviour; here it is an error the caller reports) */
+static int apply_path(pg_graph* g, const char* b, int num, const pg_step* steps, int64_t n_steps, int end_col)
 {
     const int len_b = (int)strlen(b);
     g->unsort = (int*)realloc(g->unsort, (size_t)(len_b + g->len) * sizeof(int));
@@ -180,7 +182,7 @@ static void apply_path(pg_graph* g, const char* b, int num, const pg_step* steps
         nd->out = (i + 1 < len_b) ? 1 : 0;
     }
 
-    int l = 0, cont = 0;
+    int l = 0, cont = 0, ring_full = 0;
     for (int64_t si = 0; si < n_steps; si++) {
         const int num1 = steps[si].node, num2 = steps[si].col;
         const int code = steps[si].code, peek = steps[si].peek;
@@ -270,6 +272,7 @@ static void apply_path(pg_graph* g, const char* b, int num, const pg_step* steps
                 l++;
                 pg_node* r = &g->nodes[R];
                 pg_node* x = &g->nodes[Xn];
+                if (r->ring_n >= 4) { ring_full = 1; break; }
                 r->ring_n++;
                 r->ring[r->ring_n - 1] = Xn;
                 x->ring_n = r->ring_n;
@@ -291,6 +294,12 @@ static void apply_path(pg_graph* g, const char* b, int num, const pg_step* steps
     g->unsort = (int*)realloc(g->unsort, (size_t)g->len * sizeof(int));
     g->sort = (int*)realloc(g->sort, (size_t)g->len * sizeof(int));
     free(seq);
+    if (ring_full) {
+        fprintf(stderr, "TSTA_msa: sequence %d puts a sixth distinct character into one alignment column; the reference's "
+                        "mismatch ring holds four aligned nodes besides the column's own (poa.h:109)\n", num + 1);
+        return PG_ERR_RING_FULL;
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------ control (c-t-simd.c:979-1049) */
@@ -329,7 +338,7 @@ int pg_align_and_fuse(pg_graph* g, const char* seq, int num, pg_fill_fn fill, vo
     if (rc == 0) {
         int64_t ns = 0; int32_t end_col = -1;
         pg_step* steps = walk_arrays(g, n, pred_off, pred, source, esource, fsource, lastscore, &ns, &end_col);
-        apply_path(g, seq, num, steps, ns, end_col);
+        rc = apply_path(g, seq, num, steps, ns, end_col);
         free(steps);
     }
     free(pred_off); free(pred); free(base); free(is_sink);
@@ -345,7 +354,7 @@ int pg_align_and_fuse_path(pg_graph* g, const char* seq, int num, pg_path_fn pat
     pg_step* steps = NULL; int64_t ns = 0; int32_t end_col = -1;
     void (*free_steps)(void*) = free;
     int rc = path(ctx, V, pred_off, pred, base, is_sink, (const uint8_t*)seq, n, &steps, &ns, &end_col, &free_steps);
-    if (rc == 0) apply_path(g, seq, num, steps, ns, end_col);
+    if (rc == 0) rc = apply_path(g, seq, num, steps, ns, end_col);
     if (steps) free_steps(steps);
     free(pred_off); free(pred); free(base); free(is_sink);
     return rc;

@@ -12,6 +12,7 @@
  */
 #ifndef TSTA_HOST_POA_GRAPH_H
 #define TSTA_HOST_POA_GRAPH_H
+#define PG_ERR_RING_FULL (-5)                     /* == TSTA_ERR_UNSUPPORTED: a sixth distinct character in one column */
 #include <stdint.h>
 #include <stdio.h>
 
