@@ -131,10 +131,14 @@ def config5t(eng, n_pairs=64, L=50_000):
     for i in range(n_pairs):
         a = util.random_dna(5000 + i, L)
         pairs.append((a, util.mutate(a, 6000 + i, 0.05)[:L]))
-    eng.psa_align_batch(pairs[:2])                              # warm-up
+    # a one-shot caller (TSTA_psa_batch -o): fresh engine, first call.  Device memory costs ~35 ms per GB to allocate, so the
+    # engine works in groups of <= 16 GB of trace on its first call and grows the workspace over the next calls
+    fresh = tsta_amd.Engine(0)
     t0 = time.perf_counter()
-    res = eng.psa_align_batch(pairs)
+    res = fresh.psa_align_batch(pairs)
     wall = time.perf_counter() - t0
+    fresh.close()
+    eng.psa_align_batch(pairs); eng.psa_align_batch(pairs); eng.psa_align_batch(pairs)     # grow the workspace to everything the batch wants
     k, nl = eng.last_kernel_ms()
     cells = float(sum(len(a) * len(b) for a, b in pairs))
     t0 = time.perf_counter()

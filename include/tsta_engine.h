@@ -66,10 +66,13 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_packed"     1 (default) | 0: tsta_psa_align_batch never couples two pairs per wave (packed 16-bit trace fill)
  *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream
- *   "trace_rows"       0 auto | 2 / 4      rows per lane of the trace-fill kernel
+ *   "trace_rows"       0 auto | 1 / 2 / 4  rows per lane of the trace-fill kernel (1: tsta_psa_align only)
  *   "trace_tile"       0 auto | multiple of 64: steps per tile of the trace-fill pipeline
- *   "trace_persistent" 0 (default) | 1: single-launch trace fill with flag hand-off (experiment, slower; psa_trace.hip)
+ *   "trace_persistent" 1 (default): bands that fill alone (one pair per wave) run as ONE launch, band to band hand-off through
+ *                      sc1 stores / polls without fences (psa_trace.hip) | 0: one launch per tile diagonal
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
+ *   "align_ws_gb"      0 auto (default: tsta_psa_align_batch works in groups of <= 16 GB of trace on an engine's first call,
+ *                      64 GB on the second, everything after that: device memory costs ~35 ms per GB to allocate) | cap in GB
  *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against
  *                      (default 640 = AVX512 x -W 10; the TSTA_msa drop-in passes 64 x its -W); multiple of 16, 16 .. 1048576
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */

@@ -1,6 +1,7 @@
 """GPU parity: K2 (trace fill) + K3 (walker) through tsta_psa_align vs the reference-built golden vectors
 (maxsorce + md5 of the exact output file bytes) and vs the oracle's trace().  Bit-exact."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -78,6 +79,55 @@ def test_full_size_100k_properties(eng):
     oms, oend = util.oracle_scores(x, y)
     assert ms == oms
     assert util.alignment_score(ra, rb) == oend
+
+
+def test_full_size_100k_md5_matches_reference(eng):
+    # BASELINE config #3 bit-exact at full size: the reference's own output file for this pair (tests/golden/psa_big_golden.json,
+    # made by make_big_golden.py from oracle/_ref/TSTA_psa: 62 s and 30 GB of host memory there), with the single-launch
+    # fill (default) and with the launch-per-tile pipeline
+    import hashlib
+    import json
+    with open(os.path.join(util.GOLDEN_DIR, "psa_big_golden.json")) as f:
+        g = json.load(f)
+    x = util.random_dna(g["seed_x"], g["len_x"]); y = util.mutate(x, g["seed_y"], g["rate"])
+    assert len(y) == g["len_y"]
+    try:
+        for persistent in (1, 0):
+            eng.set_option("trace_persistent", persistent)
+            ms, ra, rb = eng.psa_align(x, y)
+            data = b">1\n" + ra + b"\n>2\n" + rb                      # what TSTA_psa writes (psa.c:512-516)
+            assert ms == g["maxsorce"] and len(data) == g["size"]
+            assert hashlib.md5(data).hexdigest() == g["md5"] and hashlib.sha256(data).hexdigest() == g["sha256"], persistent
+    finally:
+        eng.set_option("trace_persistent", 1)
+
+
+def test_single_launch_fill_vs_tile_pipeline(eng):
+    # the persistent fill (sc1 hand-off between bands, tickets recycled) against the launch-per-tile pipeline and the oracle:
+    # rows per lane 1 / 2 / 4, sizes around band and block boundaries; then MANY unpaired jobs in one group (more bands
+    # than resident waves, uneven lengths: the hand-off under load)
+    try:
+        for R in (1, 2, 4):
+            eng.set_option("trace_rows", R)
+            for (l1, l2) in [(70, 64), (129, 128), (1000, 257), (3001, 2999), (9000, 8200)]:
+                a = util.random_dna(l1 * 3 + l2 + R, l1); b = util.mutate(a, l1 + R, 0.08)[:l2]
+                eng.set_option("trace_persistent", 1); got1 = eng.psa_align(a, b)
+                eng.set_option("trace_persistent", 0); got0 = eng.psa_align(a, b)
+                o = util.oracle_align(a, b)
+                assert got1 == got0 == (o[0], o[2], o[3]), (R, l1, l2)
+        eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 0)
+        pairs = []
+        for i in range(48):
+            a = util.random_dna(9100 + i, 2000 + 173 * (i % 11))
+            pairs.append((a, util.mutate(a, 9200 + i, 0.1)))
+        got = eng.psa_align_batch(pairs)
+        eng.set_option("trace_persistent", 0)
+        assert got == eng.psa_align_batch(pairs)
+        for (ms, ra, rb), (a, b) in list(zip(got, pairs))[::7]:
+            o = util.oracle_align(a, b)
+            assert (ms, ra, rb) == (o[0], o[2], o[3])
+    finally:
+        eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 1)
 
 
 def test_rows_per_lane_4_variant(eng):

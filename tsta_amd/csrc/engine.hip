@@ -205,7 +205,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     const int v = (int)value;
     if (!strcmp(key, "psa_packed") && (v == -1 || v == 0 || v == 8 || v == 16 || v == 32)) { e->opt_psa_packed = v; return TSTA_OK; }
     if (!strcmp(key, "psa_rows") && (v == 0 || v == 4 || v == 8 || v == 16)) { e->opt_psa_rows = v; return TSTA_OK; }
-    if (!strcmp(key, "trace_rows") && (v == 0 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_rows") && (v == 0 || v == 1 || v == 2 || v == 4)) { e->opt_trace_rows = v; return TSTA_OK; }
     if (!strcmp(key, "psa_elide") && (v == 0 || v == 1)) { e->opt_psa_elide = v; return TSTA_OK; }
     if (!strcmp(key, "trace_persistent") && (v == 0 || v == 1)) { e->opt_trace_persistent = v; return TSTA_OK; }
     if (!strcmp(key, "trace_streams") && (v == 0 || v == 1)) { e->opt_trace_streams = v; return TSTA_OK; }
@@ -214,6 +214,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_ffree") && (v == 0 || v == 1)) { e->opt_psa_ffree = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
+    if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
     if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;

@@ -41,6 +41,10 @@ namespace tsta {
 
 constexpr int kNegInfT = -(1 << 30);
 
+// a 64-bit word known to live in GLOBAL memory: makes the sc1 hand-off accesses global_load/store (the guide's hand-off
+// forms are measured for global_/buffer_ instructions, never flat_)
+typedef __attribute__((address_space(1))) unsigned long long GlobalU64;
+
 // sign(x) in {-1, 0, 1}: one v_med3_i32 (the compiler expands min(max(x,-1),1) into compares and selects)
 __device__ __forceinline__ int sign3(int x) { int r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x)); return r; }
 
@@ -108,7 +112,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
 }
 
-template <int R, bool PRED, bool TRACE, bool WT = false, bool FULL = false>
+template <int R, bool PRED, bool TRACE, bool WT = false, bool FULL = false>   // (WT unused: kept so call sites read the same)
 __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                             const int M, const int X, const int E, const int O, uint4* __restrict__ tq)
 {
@@ -131,33 +135,31 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
         if (TRACE) {
             const uint4 v = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
                                        (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
-            if (WT) {
-                // write-through (system-scope) stores: no dirty trace lines for the persistent form's release fences to flush
-                unsigned long long* q = reinterpret_cast<unsigned long long*>(&tq[(size_t)g * 64]);
-                __hip_atomic_store(q, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(q + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                tq[(size_t)g * 64] = v;
-            }
+            tq[(size_t)g * 64] = v;
         }
     }
 }
 
 // PERSIST = false: one tile of the launch-per-diagonal pipeline (see file header).
-// PERSIST = true: ONE launch for the whole fill.  A wave draws a ticket = its band (bands of a job are consecutive),
-// sweeps all its steps, and before each 64-step block waits until the band above has published the bottom-row entries
-// the block reads (progress[g-1] >= t0 + 128: the upper band's lane 63 trails its lane 0 by 63 columns and stores a
-// block's captures at the block's end).  Tickets are drawn in band order by waves that are already running, so the
-// band a wave waits for is held by a wave that started earlier and needs nothing from later ones: no deadlock,
-// whatever the number of resident waves.  Hand-off = global stores, agent-scope fence, relaxed atomic store of the
-// progress word; the reader polls it with s_sleep, then fences before loading.  A poll that does not end within
-// ~2^22 sleeps sets status[0] and goes on (garbage, reported by the host) so that every wave always terminates.
+// PERSIST = true: ONE launch for the whole fill.  A wave draws a ticket = its band (bands of a job are consecutive), sweeps
+// all its steps, then draws the next ticket (the grid holds one wave per SIMD; there may be more bands than that).  Before
+// each 64-step block it waits until the band above has published the bottom-row entries the block reads
+// (progress[g-1] >= t0 + 128: the upper band's lane 63 trails its lane 0 by 63 columns and stores a block's captures at the
+// block's end).  Tickets are drawn in band order by waves that are already running, so the band a wave waits for is held by
+// a wave that started earlier and needs nothing from later ones: no deadlock, whatever the number of resident waves.
+// Hand-off without fences (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table): the boundary-row entries are
+// written with sc1 (write-through) stores, the storing wave drains them (s_waitcnt vmcnt(0)) and then publishes its progress
+// word with an sc1 store; the reader polls that word with sc1 loads and, once it matches, reads the entries with sc1 loads
+// (both bypass the reader's L1; no L2 write-back, no invalidate).  Every wave signals only for its own stores.  The trace
+// bytes are plain stores: nothing reads them before the kernel ends.  A poll that does not end within ~2^22 sleeps sets
+// status[0] and goes on (garbage, reported by the host) so that every wave always terminates.
 template <int R, bool TRACE, bool PERSIST>
 __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
 {
     constexpr int NS = TraceCfg<R>::NS;
     constexpr int SPB = TraceCfg<R>::SPB;
     const int lane = threadIdx.x & 63;
+    for (;;) {
     int g;
     if (PERSIST) {
         unsigned ticket = 0;
@@ -171,13 +173,13 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.jobs[mid].band0 <= g) lo = mid; else hi = mid - 1; }
     const TraceJob& J = A.jobs[lo];
     const int w = g - J.band0;
-    if (w >= J.W) return;
+    if (w >= J.W) { if (PERSIST) continue; return; }
     const int shift = w * (A.T + 64);
     int s0 = A.d * A.T - shift, s1 = (A.d + 1) * A.T - shift;
     s0 = max(0, min(s0, J.S_total));
     s1 = max(0, min(s1, J.S_total));
     if (PERSIST) { s0 = 0; s1 = J.S_total; }
-    if (s0 >= s1) return;
+    if (s0 >= s1) { if (PERSIST) continue; return; }
 
     const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O;
     const uint8_t* __restrict__ seq_a = J.a;
@@ -213,34 +215,47 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         if (PERSIST && w > 0) {
             const int need = min(t0 + 128, J.S_total);
             int spins = 0;
-            while (__hip_atomic_load(&A.progress[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(8);
+            while (__hip_atomic_load(&A.progress[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   // sc1 poll
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 22)) { if (lane == 0) atomicOr(A.status, 1u); break; }
                 // once any wave has given up, nobody waits any more: the launch drains quickly
-                if ((spins & 255) == 0 && __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if ((spins & 1023) == 0 && __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             }
-            __threadfence();                       // acquire: the upper band's rows are visible from here on
         }
         const int c = t0 + lane;
         int2 nt = make_int2(0, 0); int na = 0;
-        if (c < n) { nt = top[c]; na = seq_a[c]; }
+        if (c < n) {
+            if (PERSIST && w > 0) {                  // handed off inside this launch: sc1 load (bypasses this CU's L1), never a plain one
+                const unsigned long long v = __hip_atomic_load((const GlobalU64*)reinterpret_cast<const unsigned long long*>(&top[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nt = make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+            } else {
+                nt = top[c];
+            }
+            na = seq_a[c];
+        }
         s.th = nt.x; s.te = nt.y; s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
         const bool steady = t0 >= 64 && t0 + 63 < n;
-        if (steady && (w + 1) * 64 * R <= m) trace_block<R, false, TRACE, PERSIST, true>(s, t0, lane, n, nvalid, M, X, E, O, tq);
-        else if (steady)                     trace_block<R, false, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
-        else                                 trace_block<R, true, TRACE, PERSIST>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        if (steady && (w + 1) * 64 * R <= m) trace_block<R, false, TRACE, false, true>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else if (steady)                     trace_block<R, false, TRACE, false>(s, t0, lane, n, nvalid, M, X, E, O, tq);
+        else                                 trace_block<R, true, TRACE, false>(s, t0, lane, n, nvalid, M, X, E, O, tq);
         const int cs = t0 - 64 + lane;
-        if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
         if (PERSIST) {
-            __threadfence();                       // release: bottom-row entries before the progress word
+            if (cs >= 0 && cs < n)                   // sc1 (write-through) store of the captured bottom-row entries
+                __hip_atomic_store((GlobalU64*)reinterpret_cast<unsigned long long*>(&bot[cs]), ((unsigned long long)(unsigned)s.se << 32) | (unsigned)s.sh,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left before its progress word does
             if (lane == 0) __hip_atomic_store(&A.progress[g], t0 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
         }
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = s.hl[k]; st[(2 * k + 1) * 64] = s.fb[k]; }
     st[(2 * R) * 64] = s.hd; st[(2 * R + 1) * 64] = s.hbot; st[(2 * R + 2) * 64] = s.ebot;
     st[(2 * R + 3) * 64] = s.cch; st[(2 * R + 4) * 64] = s.mx;
+    if (!PERSIST) return;
+    }
 }
 
 // boundary row of the matrix (psa.c:221-226) into rows[0] of every job (blockIdx.y = job)
@@ -604,7 +619,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     };
     if (persistent) {                                           // the singles' whole fill in one launch (flag hand-off)
         A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
-        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, s, A);
         ++launches;
     }
     for (int64_t d = 0; d < D; ++d) {
@@ -729,9 +744,10 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
     if (J.m > 0 && J.n > 0) {
         // rows per lane: small bands expose more concurrent bands of the single pair
         const int R_env = e->opt_trace_rows;                                                    // knob "trace_rows"
-        const int Rsel = (R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
+        const int Rsel = (R_env == 1 || R_env == 2 || R_env == 4) ? R_env : 2;   // measured on 100 kbp x 100 kbp: R=2,T=64 40 ms; R=4,T=128 50 ms
         const int T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 64;   // knob "trace_tile"
-        if (Rsel == 4) rc = run_group<4, true>(e, p, &J, 1, T);
+        if (Rsel == 1)      rc = run_group<1, true>(e, p, &J, 1, T);
+        else if (Rsel == 4) rc = run_group<4, true>(e, p, &J, 1, T);
         else           rc = run_group<2, true>(e, p, &J, 1, T);
         if (rc != TSTA_OK) return rc;
     }
@@ -786,6 +802,18 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
     const size_t held = e->in_seqs.bytes + e->rows.bytes + e->scratch.bytes + e->trace.bytes + e->scratch2.bytes + e->in_meta.bytes;
     size_t budget = (size_t)((double)(free_b + held) * 0.85);
     if (const char* v = getenv("TSTA_ALIGN_BUDGET_MB")) budget = std::min(budget, (size_t)atoll(v) << 20);
+    // Device memory costs ~35 ms per GB to allocate on this platform (measured: hipMalloc 8 / 32 / 128 GB = 0.27 / 1.2 / 4.8 s,
+    // the same through hipMemCreate; tests/tools/malloc_time.cpp), so a one-shot caller (TSTA_psa_batch -o) whose 64 pairs
+    // would like 165 GB of trace must not pay 5.7 s for 70 ms of kernels.  The workspace therefore grows over the calls of
+    // an engine: the first call works in groups of at most 16 GB (0.5 s to allocate), the next in 64 GB, then all of it;
+    // option "align_ws_gb" fixes the cap.  A workspace the engine already holds is always used in full.
+    {
+        size_t cap = e->opt_align_ws_gb > 0 ? (size_t)e->opt_align_ws_gb << 30
+                                            : (size_t)16 << (30 + 2 * std::min(e->align_calls, 8));
+        cap = std::max(cap, held);
+        budget = std::min(budget, cap);
+        ++e->align_calls;
+    }
     // (a coupled job is laid out for its couple's geometry: up to 1.25x its own cells)
     auto job_bytes = [&](const HostJob& J) { return Rsel == 4 ? JobGeom<4>(J.n, J.m, true).total() * 5 / 4 : JobGeom<2>(J.n, J.m, true).total(); };
     std::vector<HostJob> group;
@@ -812,6 +840,7 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
             continue;
         }
         const size_t need = job_bytes(J);
+        if (need > budget && need <= (size_t)((double)(free_b + held) * 0.85)) { rc = flush(); budget = need; if (rc != TSTA_OK) break; }
         if (need > budget) { e->set_error("pair %lld needs %zu bytes of device workspace, %zu available", (long long)k, need, budget); rc = TSTA_ERR_OOM; break; }
         if (used + need > budget || group.size() >= 65535) rc = flush();
         if (rc != TSTA_OK) break;
