@@ -1,0 +1,52 @@
+// handoff.h — band-to-band hand-off INSIDE one launch (the single-launch fills of psa_trace.hip / psa_trace_packed.hip).
+//
+// Form (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid forms / sc1 table):
+//   producer wave:  sc1 (write-through) stores of the boundary-row entries  ->  s_waitcnt vmcnt(0)  ->  sc1 store of its
+//                   progress word (each wave signals only for its own stores)
+//   consumer wave:  sc1-load poll of that word (bypasses its CU's L1)  ->  sc1 loads of the entries
+// No agent-scope fence on either side: no L2 write-back, no L1/L2 invalidate.  All accesses are global_* (the pointers are
+// cast to the global address space: the compiler would otherwise emit flat_*, which the guide excludes).
+// Deadlock freedom is the callers' business (bands are handed out as tickets in dependency order); a poll that does not
+// end sets a status bit and gives up, so that every wave terminates and the host reports the failure.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsta {
+
+typedef __attribute__((address_space(1))) unsigned long long GlobalU64;
+typedef __attribute__((address_space(1))) int GlobalI32;
+typedef __attribute__((address_space(1))) unsigned GlobalU32;
+
+__device__ __forceinline__ int2 load_sc1_int2(const int2* p)
+{
+    const unsigned long long v = __hip_atomic_load((const GlobalU64*)reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+}
+
+__device__ __forceinline__ void store_sc1_int2(int2* p, int x, int y)
+{
+    __hip_atomic_store((GlobalU64*)reinterpret_cast<unsigned long long*>(p), ((unsigned long long)(unsigned)y << 32) | (unsigned)x,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wait until *word >= need (word = progress of the band above)
+__device__ __forceinline__ void wait_progress(const int* word, int need, unsigned* status, int lane)
+{
+    int spins = 0;
+    while (__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if (lane == 0) atomicOr(status, 1u); break; }
+        // once any wave has given up, nobody waits any more: the launch drains quickly
+        if ((spins & 1023) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    }
+}
+
+// this wave's boundary-row stores have left; publish how far it is
+__device__ __forceinline__ void publish_progress(int* word, int value, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store((GlobalI32*)word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace tsta

@@ -34,16 +34,13 @@
 #include "../../include/tsta_engine.h"
 #include "engine.h"
 #include "wave_ops.h"
+#include "handoff.h"
 #include "trace_types.h"
 #include "kernels.h"
 
 namespace tsta {
 
 constexpr int kNegInfT = -(1 << 30);
-
-// a 64-bit word known to live in GLOBAL memory: makes the sc1 hand-off accesses global_load/store (the guide's hand-off
-// forms are measured for global_/buffer_ instructions, never flat_)
-typedef __attribute__((address_space(1))) unsigned long long GlobalU64;
 
 // sign(x) in {-1, 0, 1}: one v_med3_i32 (the compiler expands min(max(x,-1),1) into compares and selects)
 __device__ __forceinline__ int sign3(int x) { int r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x)); return r; }
@@ -212,25 +209,11 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
     uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
 
     for (int t0 = s0; t0 < s1; t0 += 64) {
-        if (PERSIST && w > 0) {
-            const int need = min(t0 + 128, J.S_total);
-            int spins = 0;
-            while (__hip_atomic_load(&A.progress[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   // sc1 poll
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { if (lane == 0) atomicOr(A.status, 1u); break; }
-                // once any wave has given up, nobody waits any more: the launch drains quickly
-                if ((spins & 1023) == 0 && __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            }
-        }
+        if (PERSIST && w > 0) wait_progress(&A.progress[g - 1], min(t0 + 128, J.S_total), A.status, lane);
         const int c = t0 + lane;
         int2 nt = make_int2(0, 0); int na = 0;
         if (c < n) {
-            if (PERSIST && w > 0) {                  // handed off inside this launch: sc1 load (bypasses this CU's L1), never a plain one
-                const unsigned long long v = __hip_atomic_load((const GlobalU64*)reinterpret_cast<const unsigned long long*>(&top[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                nt = make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
-            } else {
-                nt = top[c];
-            }
+            nt = (PERSIST && w > 0) ? load_sc1_int2(&top[c]) : top[c];      // handed off inside this launch: never a plain load
             na = seq_a[c];
         }
         s.th = nt.x; s.te = nt.y; s.ach = na;
@@ -241,11 +224,8 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         else                                 trace_block<R, true, TRACE, false>(s, t0, lane, n, nvalid, M, X, E, O, tq);
         const int cs = t0 - 64 + lane;
         if (PERSIST) {
-            if (cs >= 0 && cs < n)                   // sc1 (write-through) store of the captured bottom-row entries
-                __hip_atomic_store((GlobalU64*)reinterpret_cast<unsigned long long*>(&bot[cs]), ((unsigned long long)(unsigned)s.se << 32) | (unsigned)s.sh,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left before its progress word does
-            if (lane == 0) __hip_atomic_store(&A.progress[g], t0 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
+            publish_progress(&A.progress[g], t0 + 64, lane);
         } else {
             if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
         }
@@ -503,7 +483,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
         (rc = e->reserve(e->scratch, state_b + 256, "hipMalloc(state)")) ||
         (rc = e->reserve(e->in_meta, jobs_b + couples_b + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256 +
-                                         ((size_t)single_bands + 64) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
+                                         ((size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
         (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
         (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
@@ -516,9 +496,10 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     TraceJob* d_singles = d_jobs + n_jobs;
     TraceCouple* d_couples = reinterpret_cast<TraceCouple*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b);
     int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b + couples_b);
-    // persistent K2: [0] ticket, [1] status, [64 ...] steps completed per band
+    // single-launch fills: [0] ticket of K2, [1] status, [2] ticket of K2p, [64 ...] steps completed per band (K2's, then K2p's)
     int* d_sync = reinterpret_cast<int*>(reinterpret_cast<char*>(d_out) + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256);
     const bool persistent = n_singles > 0 && e->opt_trace_persistent != 0;
+    const bool persistent_couples = n_couples > 0 && e->opt_trace_persistent != 0;
     int sband0 = 0, cband0 = 0, max_n = 0;
     std::vector<TraceJob> singles;
     std::vector<uint8_t> h_seq(seq_b);
@@ -561,7 +542,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     PsaTraceArgs A;
     A.jobs = d_singles; A.n_jobs = n_singles; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.ticket = reinterpret_cast<unsigned*>(d_sync); A.status = reinterpret_cast<unsigned*>(d_sync + 1); A.progress = d_sync + 64;
-    if (persistent && (rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)single_bands + 64) * sizeof(int), s), "hipMemsetAsync(sync)")))
+    if ((persistent || persistent_couples) &&
+        (rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int), s), "hipMemsetAsync(sync)")))
         return rc;
     PsaTracePackedArgs B;
     B.jobs = d_jobs; B.couples = d_couples; B.n_couples = n_couples; B.T = T; B.M = p->M; B.X = p->X; B.E = p->E; B.O = p->O;
@@ -574,7 +556,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     // The couples are independent of each other: split them into up to 4 chunks with their own band numbering and
     // their own stream, so that the launch sequences overlap (one sequence's launch gaps and half-empty tails are
     // filled by the others' waves).  Chunk 0 rides on the engine's stream.
-    int n_chunks = (n_couples >= 8 && e->opt_trace_streams != 1) ? 4 : 1;
+    B.ticket = reinterpret_cast<unsigned*>(d_sync + 2); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.progress = d_sync + 64 + single_bands;
+    int n_chunks = (n_couples >= 8 && e->opt_trace_streams != 1 && !persistent_couples) ? 4 : 1;
     for (int g = 0; g + 1 < n_chunks; ++g) {
         if (!e->side[g] && hipStreamCreateWithFlags(&e->side[g], hipStreamNonBlocking) != hipSuccess) { n_chunks = 1; break; }
         if (!e->ev_join[g] && hipEventCreateWithFlags(&e->ev_join[g], hipEventDisableTiming) != hipSuccess) { n_chunks = 1; break; }
@@ -608,7 +591,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     // band w of a job may run steps below S_w(d) = (d+1)T - w(T+64) after launch d
     int64_t D = 0;
     if (!persistent) for (const TraceJob& J : singles) D = std::max<int64_t>(D, ((int64_t)J.S_total + (int64_t)(J.W - 1) * (T + 64) + T - 1) / T);
-    for (const TraceCouple& C : tc) D = std::max<int64_t>(D, ((int64_t)C.S_total + (int64_t)(C.W - 1) * (T + 64) + T - 1) / T);
+    if (!persistent_couples) for (const TraceCouple& C : tc) D = std::max<int64_t>(D, ((int64_t)C.S_total + (int64_t)(C.W - 1) * (T + 64) + T - 1) / T);
     // range of bands with work in launch d: S_w(d) > 0 and S_w(d-1) < S_total
     auto active = [&](int64_t d, int W, int S_total, int band0, int64_t& g_lo, int64_t& g_hi) {
         int64_t w_hi = ((d + 1) * T + (T + 64) - 1) / (T + 64);               // first w with S_w(d) <= 0
@@ -622,6 +605,11 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, s, A);
         ++launches;
     }
+    if (persistent_couples) {                                   // every couple's whole fill in one launch
+        B.couples = d_couples; B.n_couples = n_couples; B.d = 0; B.g_lo = 0; B.g_hi = (int)couple_bands;
+        launch_psa_trace_packed_persistent(B, couple_bands, e->n_cu, s);
+        ++launches;
+    }
     for (int64_t d = 0; d < D; ++d) {
         int64_t g_lo = single_bands, g_hi = 0;
         if (!persistent) for (const TraceJob& J : singles) active(d, J.W, J.S_total, J.band0, g_lo, g_hi);
@@ -630,7 +618,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, false>), dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, s, A);
             ++launches;
         }
-        for (int q = 0; q < n_chunks; ++q) {
+        for (int q = 0; q < n_chunks && !persistent_couples; ++q) {
             g_lo = couple_bands; g_hi = 0;
             for (int c = chunk_lo[q]; c < chunk_lo[q + 1]; ++c) active(d, tc[c].W, tc[c].S_total, tc[c].band0, g_lo, g_hi);
             if (g_lo >= g_hi) continue;
@@ -656,7 +644,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     if ((rc = e->check(hipMemcpyAsync(h_out.data(), d_out, h_out.size() * sizeof(int), hipMemcpyDeviceToHost, s), "D2H out")) ||
         (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
         return rc;
-    if (persistent) {
+    if (persistent || persistent_couples) {
         unsigned st = 0;
         if ((rc = e->check(hipMemcpy(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost), "D2H status"))) return rc;
         if (st) { e->set_error("persistent trace fill: a band waited too long for the band above (status %u)", st); return TSTA_ERR_INTERNAL; }
@@ -802,6 +790,7 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
     const size_t held = e->in_seqs.bytes + e->rows.bytes + e->scratch.bytes + e->trace.bytes + e->scratch2.bytes + e->in_meta.bytes;
     size_t budget = (size_t)((double)(free_b + held) * 0.85);
     if (const char* v = getenv("TSTA_ALIGN_BUDGET_MB")) budget = std::min(budget, (size_t)atoll(v) << 20);
+    const size_t hard_budget = budget;          // what the device (or TSTA_ALIGN_BUDGET_MB) allows at all
     // Device memory costs ~35 ms per GB to allocate on this platform (measured: hipMalloc 8 / 32 / 128 GB = 0.27 / 1.2 / 4.8 s,
     // the same through hipMemCreate; tests/tools/malloc_time.cpp), so a one-shot caller (TSTA_psa_batch -o) whose 64 pairs
     // would like 165 GB of trace must not pay 5.7 s for 70 ms of kernels.  The workspace therefore grows over the calls of
@@ -840,7 +829,7 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
             continue;
         }
         const size_t need = job_bytes(J);
-        if (need > budget && need <= (size_t)((double)(free_b + held) * 0.85)) { rc = flush(); budget = need; if (rc != TSTA_OK) break; }
+        if (need > budget && need <= hard_budget) { rc = flush(); budget = need; if (rc != TSTA_OK) break; }   // one pair larger than the soft cap
         if (need > budget) { e->set_error("pair %lld needs %zu bytes of device workspace, %zu available", (long long)k, need, budget); rc = TSTA_ERR_OOM; break; }
         if (used + need > budget || group.size() >= 65535) rc = flush();
         if (rc != TSTA_OK) break;

@@ -18,10 +18,12 @@
 // band pipeline instead of one after the other in one wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "kernels.h"
 #include "packed_ops.h"
 #include "packed_step.h"
+#include "handoff.h"
 #include "trace_types.h"
 #include "wave_ops.h"
 
@@ -151,10 +153,16 @@ struct CoupleView {
     uint8_t *tbandA, *tbandB;                   // TRACE: this band's trace bytes
     int* st;                                    // this band's per-lane state between tiles
     int w;                                      // band index
+    // single-launch form (PERSIST): progress word of the band above (nullptr: band 0) / of this band, error bits, steps per band
+    const int* prog_up; int* prog_mine; unsigned* status; int S_total;
 };
 
-// steps [s0, s1) of one band of one couple
-template <int R, bool TRACE, bool PERM, bool FF = false>
+// steps [s0, s1) of one band of one couple.  PERSIST: the whole band in one go inside a single launch; the band above
+// runs concurrently in another wave of the same launch and its bottom row is handed over as handoff.h describes: this
+// wave waits for the upper band's progress word before every 64-step block and reads the block's top-row entries with sc1
+// loads at the START of the block (not one block ahead as the launch-per-tile form does: that would lengthen the distance
+// a band must keep to the one above by 64 steps).
+template <int R, bool TRACE, bool PERM, bool FF = false, bool PERSIST = false>
 __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
                                             const int M, const int E, const int O,
                                             const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
@@ -204,6 +212,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     int2* __restrict__ botB = V.botB;
     // top-row entry of column c: from the band above, or the matrix boundary row H(0,c+1) = O + (c+1)E, Ebar = H + O
     auto top_entry = [&](const int2* __restrict__ top, int c) -> int2 {
+        if (PERSIST && top && w > 0) return load_sc1_int2(&top[c]);     // handed off inside this launch: never a plain load
         if (top) return top[c];
         const int h = O + (c + 1) * E;
         return make_int2(h, h + O);
@@ -241,11 +250,19 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     // launch may read of the band above was written by earlier launches)
     int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
     int naA = 0, naB = 0;
-    { const int c = s0 + opaque(lane); if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; } if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; } }
+    if (!PERSIST) { const int c = s0 + opaque(lane); if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; } if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; } }
     int lag = 64;                                  // columns moved since the H* frame's reference column was set
     for (int t0 = s0; t0 < s1; t0 += 64) {
         const int ln = opaque(lane);
         lag = 64;
+        if (PERSIST) {
+            // the upper band publishes a block's captures (columns t0 .. t0+63) at the end of ITS block t0+64
+            if (V.prog_up) wait_progress(V.prog_up, min(t0 + 128, V.S_total), V.status, lane);
+            const int c = t0 + ln;
+            ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
+            if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; }
+            if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; }
+        }
         if (t0 > 0 && t0 < n) {
             // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
             fold_mx(s.mx, acc);
@@ -273,7 +290,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         unsigned tabA = 0u, tabB = 0u;                 // this block's column tables (PERM) / characters
         if (PERM) { tabA = acgt_table(naA, k4); tabB = acgt_table(naB, k4); }
         else      tabA = pack2(naA << 8, naB << 8);
-        if (t0 + 64 < s1) {
+        if (!PERSIST && t0 + 64 < s1) {
             const int cn = t0 + 64 + ln;
             ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
             if (cn < nA) { ntA = top_entry(topA, cn); naA = aA[cn]; }
@@ -326,9 +343,12 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         const int cs = t0 - 64 + ln;
         if (V.store_bottom && cs >= 0 && cs < n) {
             const int sh_m = (cs + 1) * M;
-            botA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
-            botB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
+            const int hA = (int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, eA = (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m;
+            const int hB = (int)(s.sh >> 16) - kBias + acc.baseB + sh_m, eB = (int)(s.se >> 16) - kBias + acc.baseB + sh_m;
+            if (PERSIST) { store_sc1_int2(&botA[cs], hA, eA); store_sc1_int2(&botB[cs], hB, eB); }
+            else         { botA[cs] = make_int2(hA, eA); botB[cs] = make_int2(hB, eB); }
         }
+        if (PERSIST && V.store_bottom) publish_progress(V.prog_mine, t0 + 64, lane);
     }
     fold_mx(s.mx, acc);
 #pragma unroll
@@ -341,23 +361,35 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     if (PERM) st[(2 * R + 9) * 64] = (int)s.cch2;
 }
 
-template <int R>
+// PERSIST = false: one tile of the launch-per-diagonal pipeline.  PERSIST = true: one launch for the whole fill of every
+// couple of the group: waves draw bands as tickets in band order (so the band a wave waits for is always held by a wave
+// that started earlier: no deadlock whatever the number of resident waves) and sweep them from the first step to the last.
+template <int R, bool PERSIST>
 __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePackedArgs A)
 {
     constexpr int NS = packed_state_ints(R);
     const int lane = threadIdx.x & 63;
-    const int g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (;;) {
+    int g;
+    if (PERSIST) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(A.ticket, 1u);
+        g = (int)__builtin_amdgcn_readfirstlane(ticket);
+    } else {
+        g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    }
     if (g >= A.g_hi) return;
     int lo = 0, hi = A.n_couples - 1;           // couple = last one whose first band is <= g
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.couples[mid].band0 <= g) lo = mid; else hi = mid - 1; }
     const TraceCouple& C = A.couples[lo];
     const int w = g - C.band0;
-    if (w >= C.W) return;
+    if (w >= C.W) { if (PERSIST) continue; return; }
     const int shift = w * (A.T + 64);
     int s0 = A.d * A.T - shift, s1 = (A.d + 1) * A.T - shift;
     s0 = max(0, min(s0, C.S_total));
     s1 = max(0, min(s1, C.S_total));
-    if (s0 >= s1) return;
+    if (PERSIST) { s0 = 0; s1 = C.S_total; }
+    if (s0 >= s1) { if (PERSIST) continue; return; }
 
     const TraceJob& JA = A.jobs[C.ja];
     const TraceJob& JB = A.jobs[C.jb];
@@ -370,8 +402,12 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
     V.tbandA = JA.trace + (size_t)w * JA.band_bytes; V.tbandB = JB.trace + (size_t)w * JB.band_bytes;
     V.st = C.state + (size_t)w * NS * 64;
     V.w = w;
-    if (C.perm) packed_tile<R, true, true>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
-    else        packed_tile<R, true, false>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
+    V.prog_up = (PERSIST && w > 0) ? A.progress + (g - 1) : nullptr; V.prog_mine = PERSIST ? A.progress + g : nullptr;
+    V.status = A.status; V.S_total = C.S_total;
+    if (C.perm) packed_tile<R, true, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
+    else        packed_tile<R, true, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
+    if (!PERSIST) return;
+    }
 }
 
 // per couple (blockIdx.x): out[0] of both jobs = max over all lanes' running maxima, floored at -100 (psa.c:590)
@@ -439,6 +475,7 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     V.tbandA = nullptr; V.tbandB = nullptr;
     V.st = P.state + ((size_t)c * P.W_max + w) * NS * 64;
     V.w = w;
+    V.prog_up = nullptr; V.prog_mine = nullptr; V.status = nullptr; V.S_total = S_total;
     // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
     const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
     if (perm && P.ffree) packed_tile<R, false, true, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
@@ -488,7 +525,20 @@ void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t 
 
 void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL((psa_trace_packed_tile_kernel<kPackedTraceR>), dim3(blocks), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((psa_trace_packed_tile_kernel<kPackedTraceR, false>), dim3(blocks), dim3(256), 0, stream, args);
+}
+
+// the single-launch form: as many 256-thread blocks as stay resident (or fewer, if there are fewer bands)
+void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int64_t bands, int n_cu, hipStream_t stream)
+{
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_trace_packed_tile_kernel<kPackedTraceR, true>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb > 2 ? 2 : nb;            // two waves per SIMD already issue at the full rate
+    }
+    const int64_t blocks = std::min<int64_t>((bands + 3) / 4, (int64_t)n_cu * per_cu);
+    hipLaunchKernelGGL((psa_trace_packed_tile_kernel<kPackedTraceR, true>), dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, stream, args);
 }
 
 void launch_psa_trace_packed_finish(const TraceJob* jobs, const TraceCouple* couples, int n_couples, hipStream_t stream)

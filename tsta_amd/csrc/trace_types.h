@@ -52,6 +52,8 @@ struct PsaTracePackedArgs {
     int M, X, E, O;
     unsigned pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
     int elide;                      // 1: blocks that provably cannot raise the maximum drop the running max (packed_step.h)
+    // single-launch form (handoff.h): ticket word, steps completed per band (indexed by band number), error bits
+    unsigned* ticket; int* progress; unsigned* status;
 };
 
 // ints of per-lane state a packed band keeps between tiles: hl/fb[R], hd, hbot, ebot, cch, mxA, mxB, baseA, baseB, in_star, cch2
@@ -59,6 +61,7 @@ constexpr int packed_state_ints(int R) { return 2 * R + 10; }
 
 constexpr int kPackedTraceR = 4;    // rows per lane of the packed trace fill (trace layout = TraceCfg<4>)
 void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream);
+void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int64_t bands, int n_cu, hipStream_t stream);
 void launch_psa_trace_packed_finish(const TraceJob* jobs, const TraceCouple* couples, int n_couples, hipStream_t stream);
 
 }  // namespace tsta
