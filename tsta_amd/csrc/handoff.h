@@ -24,22 +24,45 @@ __device__ __forceinline__ int2 load_sc1_int2(const int2* p)
     return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
 }
 
+__device__ __forceinline__ int load_sc1_int(const int* p)
+{
+    return __hip_atomic_load((const GlobalI32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_sc1_int(int* p, int v)
+{
+    __hip_atomic_store((GlobalI32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void store_sc1_int2(int2* p, int x, int y)
 {
     __hip_atomic_store((GlobalU64*)reinterpret_cast<unsigned long long*>(p), ((unsigned long long)(unsigned)y << 32) | (unsigned)x,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// wait until *word >= need (word = progress of the band above)
+// wait until *word >= need (word = progress of the band above, in steps).  The poll backs off with the distance still
+// to go: a band parked far behind the one above (pipeline ramp-up) looks once per ~3.4 us per 128 steps of distance instead
+// of hammering the fabric (thousands of waves polling every 100 cycles cost the working waves more than the launches this
+// form removes: measured, 64 x 50 kbp pairs 120 -> 88 ms); close to the goal it looks every ~130 cycles.
 __device__ __forceinline__ void wait_progress(const int* word, int need, unsigned* status, int lane)
 {
     int spins = 0;
-    while (__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { if (lane == 0) atomicOr(status, 1u); break; }
+    for (;;) {
+        const int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (cur >= need) break;
+        const int far = (need - cur) >> 7;                      // 64-step blocks take >= 12 us: 3.4 us of sleep per 128 steps is safe
+        if (far > 0) { for (int i = 0; i < min(far, 32); ++i) __builtin_amdgcn_s_sleep(127); }
+        else __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 20)) { if (lane == 0) atomicOr(status, 1u); break; }
         // once any wave has given up, nobody waits any more: the launch drains quickly
-        if ((spins & 1023) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if ((spins & 255) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }
+}
+
+// one look at the word, no waiting (wave-uniform answer)
+__device__ __forceinline__ bool progress_reached(const int* word, int need)
+{
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= need;
 }
 
 // this wave's boundary-row stores have left; publish how far it is

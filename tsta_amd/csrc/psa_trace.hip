@@ -467,10 +467,11 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
 
     std::vector<TraceJob> tj((size_t)n_jobs);
     size_t rows_b = 0, state_b = 0, trace_b = 0, ops_b = 0, seq_b = 0;
-    int64_t single_bands = 0, couple_bands = 0;
+    int64_t single_bands = 0, couple_bands = 0, d_bound = 0;    // d_bound: tile diagonals ("launches") of the longest couple
     int n_singles = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const JobGeom<R> g(jobs[j].n, jobs[j].m, lay_n[j], lay_m[j], TRACE);
+        if (couple_of[j] >= 0) d_bound = std::max<int64_t>(d_bound, ((int64_t)g.S_total + (int64_t)(g.W - 1) * (T + 64) + T - 1) / T);
         rows_b += g.rows_bytes; trace_b += g.trace_bytes; ops_b += g.ops_bytes; seq_b += g.seq_bytes;
         if (couple_of[j] < 0) { state_b += g.state_bytes; single_bands += g.W; ++n_singles; }
         else if (tc[couple_of[j]].ja == j) { state_b += (size_t)g.W * NSP * 64 * sizeof(int); couple_bands += g.W; }
@@ -483,7 +484,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
         (rc = e->reserve(e->scratch, state_b + 256, "hipMalloc(state)")) ||
         (rc = e->reserve(e->in_meta, jobs_b + couples_b + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256 +
-                                         ((size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
+                                         ((size_t)single_bands + (size_t)couple_bands + 2 * (size_t)d_bound + 256) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
         (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
         (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
@@ -498,7 +499,9 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     int* d_out = reinterpret_cast<int*>(reinterpret_cast<char*>(e->in_meta.p) + jobs_b + couples_b);
     // single-launch fills: [0] ticket of K2, [1] status, [2] ticket of K2p, [64 ...] steps completed per band (K2's, then K2p's)
     int* d_sync = reinterpret_cast<int*>(reinterpret_cast<char*>(d_out) + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256);
-    const bool persistent = n_singles > 0 && e->opt_trace_persistent != 0;
+    // one pair per wave: a wave owns a band from its first step to its last (psa_trace_tile_kernel<.., PERSIST>) — right for the
+    // single-pair calls, whose bands are few and all on the critical path; many unpaired jobs keep the launch pipeline
+    const bool persistent = n_singles == 1 && e->opt_trace_persistent != 0;
     const bool persistent_couples = n_couples > 0 && e->opt_trace_persistent != 0;
     int sband0 = 0, cband0 = 0, max_n = 0;
     std::vector<TraceJob> singles;
@@ -557,6 +560,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     // their own stream, so that the launch sequences overlap (one sequence's launch gaps and half-empty tails are
     // filled by the others' waves).  Chunk 0 rides on the engine's stream.
     B.ticket = reinterpret_cast<unsigned*>(d_sync + 2); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.progress = d_sync + 64 + single_bands;
+    B.tile_first = nullptr; B.tile_glo = nullptr; B.n_d = 0; B.n_tiles = 0;
     int n_chunks = (n_couples >= 8 && e->opt_trace_streams != 1 && !persistent_couples) ? 4 : 1;
     for (int g = 0; g + 1 < n_chunks; ++g) {
         if (!e->side[g] && hipStreamCreateWithFlags(&e->side[g], hipStreamNonBlocking) != hipSuccess) { n_chunks = 1; break; }
@@ -605,9 +609,28 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, s, A);
         ++launches;
     }
-    if (persistent_couples) {                                   // every couple's whole fill in one launch
+    std::vector<int> tile_tab;                                  // [first tile of d ...][D + 1], then [g_lo(d) ...][D]
+    if (persistent_couples) {
+        // every couple's whole fill as ONE launch in dataflow form: the tiles of the launch pipeline, enumerated d-major
+        int64_t Dc = 0;
+        for (const TraceCouple& C : tc) Dc = std::max<int64_t>(Dc, ((int64_t)C.S_total + (int64_t)(C.W - 1) * (T + 64) + T - 1) / T);
+        if (Dc > d_bound) return TSTA_ERR_INTERNAL;
+        tile_tab.assign((size_t)(2 * Dc + 1), 0);
+        int64_t total = 0;
+        for (int64_t d = 0; d < Dc; ++d) {
+            int64_t g_lo = couple_bands, g_hi = 0;
+            for (const TraceCouple& C : tc) active(d, C.W, C.S_total, C.band0, g_lo, g_hi);
+            if (g_lo >= g_hi) { g_lo = 0; g_hi = 0; }
+            tile_tab[(size_t)d] = (int)total; tile_tab[(size_t)(Dc + 1 + d)] = (int)g_lo;
+            total += g_hi - g_lo;
+            if (total > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
+        }
+        tile_tab[(size_t)Dc] = (int)total;
+        int* d_tab = d_sync + single_bands + couple_bands + 128;          // behind the words the memset above clears
+        if ((rc = e->check(hipMemcpyAsync(d_tab, tile_tab.data(), tile_tab.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D tile table"))) return rc;
         B.couples = d_couples; B.n_couples = n_couples; B.d = 0; B.g_lo = 0; B.g_hi = (int)couple_bands;
-        launch_psa_trace_packed_persistent(B, couple_bands, e->n_cu, s);
+        B.tile_first = d_tab; B.tile_glo = d_tab + Dc + 1; B.n_d = (int)Dc; B.n_tiles = (int)total;
+        launch_psa_trace_packed_persistent(B, e->n_cu, s);
         ++launches;
     }
     for (int64_t d = 0; d < D; ++d) {

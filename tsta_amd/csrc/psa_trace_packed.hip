@@ -18,6 +18,7 @@
 // band pipeline instead of one after the other in one wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 
 #include "kernels.h"
@@ -153,15 +154,12 @@ struct CoupleView {
     uint8_t *tbandA, *tbandB;                   // TRACE: this band's trace bytes
     int* st;                                    // this band's per-lane state between tiles
     int w;                                      // band index
-    // single-launch form (PERSIST): progress word of the band above (nullptr: band 0) / of this band, error bits, steps per band
-    const int* prog_up; int* prog_mine; unsigned* status; int S_total;
 };
 
-// steps [s0, s1) of one band of one couple.  PERSIST: the whole band in one go inside a single launch; the band above
-// runs concurrently in another wave of the same launch and its bottom row is handed over as handoff.h describes: this
-// wave waits for the upper band's progress word before every 64-step block and reads the block's top-row entries with sc1
-// loads at the START of the block (not one block ahead as the launch-per-tile form does: that would lengthen the distance
-// a band must keep to the one above by 64 steps).
+// steps [s0, s1) of one band of one couple.  PERSIST: the tile runs inside the single-launch (dataflow) form: the tiles
+// it depends on ran in OTHER waves of the same launch, so everything it exchanges with them — top row in, bottom row
+// out, the band's lane state in and out — goes through sc1 loads / stores (handoff.h); the kernel around it waits for the
+// two producer tiles before and publishes this band's progress after.
 template <int R, bool TRACE, bool PERM, bool FF = false, bool PERSIST = false>
 __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
                                             const int M, const int E, const int O,
@@ -212,7 +210,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     int2* __restrict__ botB = V.botB;
     // top-row entry of column c: from the band above, or the matrix boundary row H(0,c+1) = O + (c+1)E, Ebar = H + O
     auto top_entry = [&](const int2* __restrict__ top, int c) -> int2 {
-        if (PERSIST && top && w > 0) return load_sc1_int2(&top[c]);     // handed off inside this launch: never a plain load
+        if (PERSIST && top && w > 0) return load_sc1_int2(&top[c]);     // written inside this launch by another wave: never a plain load
         if (top) return top[c];
         const int h = O + (c + 1) * E;
         return make_int2(h, h + O);
@@ -233,14 +231,15 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
         s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.cch2 = 0u;
     } else {
+        auto ld = [&](int idx) -> int { return PERSIST ? load_sc1_int(&st[idx * 64]) : st[idx * 64]; };
 #pragma unroll
-        for (int k = 0; k < R; ++k) { s.hl[k] = (unsigned)st[(2 * k) * 64]; s.fb[k] = (unsigned)st[(2 * k + 1) * 64]; }
-        s.hd = (unsigned)st[(2 * R) * 64]; s.hbot = (unsigned)st[(2 * R + 1) * 64]; s.ebot = (unsigned)st[(2 * R + 2) * 64];
-        s.cch = (unsigned)st[(2 * R + 3) * 64];
-        if (PERM) s.cch2 = (unsigned)st[(2 * R + 9) * 64];
-        in_star = __builtin_amdgcn_readfirstlane(st[(2 * R + 8) * 64]) != 0;
-        acc.mxA = st[(2 * R + 4) * 64]; acc.mxB = st[(2 * R + 5) * 64];
-        acc.baseA = __builtin_amdgcn_readfirstlane(st[(2 * R + 6) * 64]); acc.baseB = __builtin_amdgcn_readfirstlane(st[(2 * R + 7) * 64]);
+        for (int k = 0; k < R; ++k) { s.hl[k] = (unsigned)ld(2 * k); s.fb[k] = (unsigned)ld(2 * k + 1); }
+        s.hd = (unsigned)ld(2 * R); s.hbot = (unsigned)ld(2 * R + 1); s.ebot = (unsigned)ld(2 * R + 2);
+        s.cch = (unsigned)ld(2 * R + 3);
+        if (PERM) s.cch2 = (unsigned)ld(2 * R + 9);
+        in_star = __builtin_amdgcn_readfirstlane(ld(2 * R + 8)) != 0;
+        acc.mxA = ld(2 * R + 4); acc.mxB = ld(2 * R + 5);
+        acc.baseA = __builtin_amdgcn_readfirstlane(ld(2 * R + 6)); acc.baseB = __builtin_amdgcn_readfirstlane(ld(2 * R + 7));
     }
     s.sh = pack2(kBias, kBias); s.se = s.sh; s.mx = 0u; s.ach2 = 0u;
     if (!PERM) s.cch2 = 0u;
@@ -250,19 +249,11 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     // launch may read of the band above was written by earlier launches)
     int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
     int naA = 0, naB = 0;
-    if (!PERSIST) { const int c = s0 + opaque(lane); if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; } if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; } }
+    { const int c = s0 + opaque(lane); if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; } if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; } }
     int lag = 64;                                  // columns moved since the H* frame's reference column was set
     for (int t0 = s0; t0 < s1; t0 += 64) {
         const int ln = opaque(lane);
         lag = 64;
-        if (PERSIST) {
-            // the upper band publishes a block's captures (columns t0 .. t0+63) at the end of ITS block t0+64
-            if (V.prog_up) wait_progress(V.prog_up, min(t0 + 128, V.S_total), V.status, lane);
-            const int c = t0 + ln;
-            ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
-            if (c < nA) { ntA = top_entry(topA, c); naA = aA[c]; }
-            if (c < nB) { ntB = top_entry(topB, c); naB = aB[c]; }
-        }
         if (t0 > 0 && t0 < n) {
             // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
             fold_mx(s.mx, acc);
@@ -290,7 +281,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         unsigned tabA = 0u, tabB = 0u;                 // this block's column tables (PERM) / characters
         if (PERM) { tabA = acgt_table(naA, k4); tabB = acgt_table(naB, k4); }
         else      tabA = pack2(naA << 8, naB << 8);
-        if (!PERSIST && t0 + 64 < s1) {
+        if (t0 + 64 < s1) {
             const int cn = t0 + 64 + ln;
             ntA = make_int2(0, 0); ntB = make_int2(0, 0); naA = 0; naB = 0;
             if (cn < nA) { ntA = top_entry(topA, cn); naA = aA[cn]; }
@@ -348,47 +339,57 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             if (PERSIST) { store_sc1_int2(&botA[cs], hA, eA); store_sc1_int2(&botB[cs], hB, eB); }
             else         { botA[cs] = make_int2(hA, eA); botB[cs] = make_int2(hB, eB); }
         }
-        if (PERSIST && V.store_bottom) publish_progress(V.prog_mine, t0 + 64, lane);
     }
     fold_mx(s.mx, acc);
+    auto sv = [&](int idx, int v) { if (PERSIST) store_sc1_int(&st[idx * 64], v); else st[idx * 64] = v; };
 #pragma unroll
-    for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = (int)s.hl[k]; st[(2 * k + 1) * 64] = (int)s.fb[k]; }
-    st[(2 * R) * 64] = (int)s.hd; st[(2 * R + 1) * 64] = (int)s.hbot; st[(2 * R + 2) * 64] = (int)s.ebot;
-    st[(2 * R + 3) * 64] = (int)s.cch;
-    st[(2 * R + 4) * 64] = acc.mxA; st[(2 * R + 5) * 64] = acc.mxB;
-    st[(2 * R + 6) * 64] = acc.baseA; st[(2 * R + 7) * 64] = acc.baseB;
-    st[(2 * R + 8) * 64] = in_star ? 1 : 0;
-    if (PERM) st[(2 * R + 9) * 64] = (int)s.cch2;
+    for (int k = 0; k < R; ++k) { sv(2 * k, (int)s.hl[k]); sv(2 * k + 1, (int)s.fb[k]); }
+    sv(2 * R, (int)s.hd); sv(2 * R + 1, (int)s.hbot); sv(2 * R + 2, (int)s.ebot);
+    sv(2 * R + 3, (int)s.cch);
+    sv(2 * R + 4, acc.mxA); sv(2 * R + 5, acc.mxB);
+    sv(2 * R + 6, acc.baseA); sv(2 * R + 7, acc.baseB);
+    sv(2 * R + 8, in_star ? 1 : 0);
+    if (PERM) sv(2 * R + 9, (int)s.cch2);
 }
 
-// PERSIST = false: one tile of the launch-per-diagonal pipeline.  PERSIST = true: one launch for the whole fill of every
-// couple of the group: waves draw bands as tickets in band order (so the band a wave waits for is always held by a wave
-// that started earlier: no deadlock whatever the number of resident waves) and sweep them from the first step to the last.
+// PERSIST = false: one tile of the launch-per-diagonal pipeline (launch d advances every band by one T-step tile).
+// PERSIST = true: the SAME tiles as one launch, in dataflow form.  Tickets enumerate the tiles in the order the launch
+// pipeline runs them (d-major: tile_first[d] .. tile_first[d+1] are the bands [g_lo(d), g_hi(d)) of "launch" d); a wave
+// takes a ticket, waits until the two tiles it depends on have published — the band's own previous tile (progress[g] >= s0)
+// and the tile of the band above that ends 64 steps later (progress[g-1] >= s1 + 64) — runs the tile and publishes
+// progress[g] = s1.  Both producers belong to "launch" d-1, i.e. hold earlier tickets and are finished or running: no
+// deadlock whatever the number of resident waves.  Unlike the launches, a slow tile delays only its dependents, and there
+// are no launch gaps; unlike a wave-per-band form, every resident wave always has runnable work (measured on 64 pairs of
+// 50 kbp: wave-per-band 88-99 ms, launches 72 ms on free hardware queues / 99 ms when the process has other streams).
 template <int R, bool PERSIST>
-__global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePackedArgs A)
+__global__ __launch_bounds__(256, 4) void psa_trace_packed_tile_kernel(PsaTracePackedArgs A)
 {
     constexpr int NS = packed_state_ints(R);
     const int lane = threadIdx.x & 63;
     for (;;) {
-    int g;
+    int g, d = A.d;
     if (PERSIST) {
         unsigned ticket = 0;
         if (lane == 0) ticket = atomicAdd(A.ticket, 1u);
-        g = (int)__builtin_amdgcn_readfirstlane(ticket);
+        const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
+        if (t >= A.n_tiles) return;
+        int lo = 0, hi = A.n_d - 1;             // d = last one whose first tile is <= t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.tile_first[mid] <= t) lo = mid; else hi = mid - 1; }
+        d = lo;
+        g = A.tile_glo[d] + (t - A.tile_first[d]);
     } else {
         g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (g >= A.g_hi) return;
     }
-    if (g >= A.g_hi) return;
     int lo = 0, hi = A.n_couples - 1;           // couple = last one whose first band is <= g
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.couples[mid].band0 <= g) lo = mid; else hi = mid - 1; }
     const TraceCouple& C = A.couples[lo];
     const int w = g - C.band0;
     if (w >= C.W) { if (PERSIST) continue; return; }
     const int shift = w * (A.T + 64);
-    int s0 = A.d * A.T - shift, s1 = (A.d + 1) * A.T - shift;
+    int s0 = d * A.T - shift, s1 = (d + 1) * A.T - shift;
     s0 = max(0, min(s0, C.S_total));
     s1 = max(0, min(s1, C.S_total));
-    if (PERSIST) { s0 = 0; s1 = C.S_total; }
     if (s0 >= s1) { if (PERSIST) continue; return; }
 
     const TraceJob& JA = A.jobs[C.ja];
@@ -402,11 +403,14 @@ __global__ __launch_bounds__(256) void psa_trace_packed_tile_kernel(PsaTracePack
     V.tbandA = JA.trace + (size_t)w * JA.band_bytes; V.tbandB = JB.trace + (size_t)w * JB.band_bytes;
     V.st = C.state + (size_t)w * NS * 64;
     V.w = w;
-    V.prog_up = (PERSIST && w > 0) ? A.progress + (g - 1) : nullptr; V.prog_mine = PERSIST ? A.progress + g : nullptr;
-    V.status = A.status; V.S_total = C.S_total;
+    if (PERSIST) {
+        if (s0 > 0) wait_progress(A.progress + g, s0, A.status, lane);                                  // this band's previous tile
+        if (w > 0)  wait_progress(A.progress + g - 1, min(s1 + 64, C.S_total), A.status, lane);         // the band above, 64 steps further
+    }
     if (C.perm) packed_tile<R, true, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
     else        packed_tile<R, true, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
     if (!PERSIST) return;
+    publish_progress(A.progress + g, s1, lane);
     }
 }
 
@@ -475,7 +479,6 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     V.tbandA = nullptr; V.tbandB = nullptr;
     V.st = P.state + ((size_t)c * P.W_max + w) * NS * 64;
     V.w = w;
-    V.prog_up = nullptr; V.prog_mine = nullptr; V.status = nullptr; V.S_total = S_total;
     // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
     const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
     if (perm && P.ffree) packed_tile<R, false, true, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
@@ -528,16 +531,16 @@ void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hi
     hipLaunchKernelGGL((psa_trace_packed_tile_kernel<kPackedTraceR, false>), dim3(blocks), dim3(256), 0, stream, args);
 }
 
-// the single-launch form: as many 256-thread blocks as stay resident (or fewer, if there are fewer bands)
-void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int64_t bands, int n_cu, hipStream_t stream)
+// the single-launch (dataflow) form: as many 256-thread blocks as stay resident (or fewer, if there are fewer tiles)
+void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int n_cu, hipStream_t stream)
 {
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_trace_packed_tile_kernel<kPackedTraceR, true>, 256, 0) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb > 2 ? 2 : nb;            // two waves per SIMD already issue at the full rate
+        per_cu = nb > 2 ? 2 : nb;            // measured (64 pairs of 50 kbp): 2 blocks per CU 72-74 ms, 3: 75-81, 4: 81
     }
-    const int64_t blocks = std::min<int64_t>((bands + 3) / 4, (int64_t)n_cu * per_cu);
+    const int64_t blocks = std::min<int64_t>(((int64_t)args.n_tiles + 3) / 4, (int64_t)n_cu * per_cu);
     hipLaunchKernelGGL((psa_trace_packed_tile_kernel<kPackedTraceR, true>), dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, stream, args);
 }
 

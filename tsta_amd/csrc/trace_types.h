@@ -54,6 +54,8 @@ struct PsaTracePackedArgs {
     int elide;                      // 1: blocks that provably cannot raise the maximum drop the running max (packed_step.h)
     // single-launch form (handoff.h): ticket word, steps completed per band (indexed by band number), error bits
     unsigned* ticket; int* progress; unsigned* status;
+    // ... its tiles in the order the launch pipeline runs them: "launch" d = tiles tile_first[d] .. tile_first[d+1] = bands tile_glo[d] ...
+    const int* tile_first; const int* tile_glo; int n_d, n_tiles;
 };
 
 // ints of per-lane state a packed band keeps between tiles: hl/fb[R], hd, hbot, ebot, cch, mxA, mxB, baseA, baseB, in_star, cch2
@@ -61,7 +63,7 @@ constexpr int packed_state_ints(int R) { return 2 * R + 10; }
 
 constexpr int kPackedTraceR = 4;    // rows per lane of the packed trace fill (trace layout = TraceCfg<4>)
 void launch_psa_trace_packed_tile(const PsaTracePackedArgs& args, int blocks, hipStream_t stream);
-void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int64_t bands, int n_cu, hipStream_t stream);
+void launch_psa_trace_packed_persistent(const PsaTracePackedArgs& args, int n_cu, hipStream_t stream);
 void launch_psa_trace_packed_finish(const TraceJob* jobs, const TraceCouple* couples, int n_couples, hipStream_t stream);
 
 }  // namespace tsta
