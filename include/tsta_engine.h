@@ -73,6 +73,8 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
  *   "align_ws_gb"      0 auto (default: tsta_psa_align_batch works in groups of <= 16 GB of trace on an engine's first call,
  *                      64 GB on the second, everything after that: device memory costs ~35 ms per GB to allocate) | cap in GB
+ *   "poa_dataflow"     1 (default): POA fill as one launch, tiles handed out as tickets, a solver wave + three emitter waves per
+ *                      tile (poa_dataflow.hip; sequences <= 16384 without 'N') | 0: always one launch per tile anti-diagonal
  *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against
  *                      (default 640 = AVX512 x -W 10; the TSTA_msa drop-in passes 64 x its -W); multiple of 16, 16 .. 1048576
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */

@@ -86,6 +86,25 @@ def test_four_columns_per_lane_variant(eng):
         eng.set_option("poa_cols", 0)
 
 
+def test_launch_per_diagonal_variant(eng):
+    # the default for these sizes is the single-launch dataflow fill (poa_dataflow.hip: solver + emitter waves); the
+    # launch-per-anti-diagonal K4 (which also serves sequences with 'N' and > 16384 columns) must give the same bytes
+    try:
+        eng.set_option("poa_dataflow", 0)
+        for path in FIXTURES[:4] + FIXTURES[-4:]:
+            z, sc = load(path)
+            best, last, src, es, fs = eng.poa_fill(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"],
+                                                   tsta_amd.Params(**sc))
+            check_against_fixture(z, best, last, src, es, fs)
+        for seed, V, mp, n in [(3, 64, 41, 700), (5, 700, 12, 8193), (7, 400, 2, 1025)]:
+            pred_off, pred, base, is_sink, seq = random_dag(seed, V, mp, n)
+            got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+            want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
+    finally:
+        eng.set_option("poa_dataflow", 1)
+
+
 def test_rejects_bad_dags(eng):
     base = np.frombuffer(b"ACG", np.uint8); sink = np.array([0, 0, 1], np.uint8); seq = util.random_dna(1, 10)
     with pytest.raises(tsta_amd.TstaError):       # predecessor not earlier in topological order

@@ -604,6 +604,17 @@ static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const u
     return e->warn[0] ? TSTA_WARN_REFERENCE_UNDEFINED : TSTA_OK;
 }
 
+// after the stream has been synchronised: did every wait of the dataflow fill end?
+static int poa_dataflow_status(Engine* e)
+{
+    if (!e->poa_status) return TSTA_OK;
+    unsigned st = 0;
+    int rc = e->check(hipMemcpy(&st, e->poa_status, sizeof(st), hipMemcpyDeviceToHost), "D2H poa status");
+    if (rc != TSTA_OK) return rc;
+    if (st) { e->set_error("POA dataflow fill: a tile waited too long for its producers (status %u)", st); return TSTA_ERR_INTERNAL; }
+    return TSTA_OK;
+}
+
 // Validation, uploads, workspace and the fill launches; leaves everything on the device.
 static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
                              bool want_trace, PoaArgs& A)
@@ -657,7 +668,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)")) ||
         (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)")) ||
         (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)")) ||
-        (rc = e->reserve(e->scratch, (size_t)V * (nchunks + 1) * 4 + 64, "hipMalloc(poa carry)")) ||
+        (rc = e->reserve(e->scratch, 3 * (size_t)V * (nchunks + 1) * 4 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)")) ||
         (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)")))
         return rc;
     if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)"))) return rc;
@@ -697,9 +708,24 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.best = reinterpret_cast<int*>(e->counter.p);
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
 
+    // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
+    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && memchr(seq, 'N', (size_t)n) == nullptr;
     e->timing_begin(s);
     hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
     int launches = 1;
+    if (dataflow) {
+        const size_t per = (size_t)V * (nchunks + 1);
+        int* d_edge = A.carry + per;
+        int* d_cflag32 = d_edge + per;
+        int* d_work = d_cflag32 + per;
+        const size_t work_ints = (size_t)2 * (nchunks + nrb) + nchunks + 64;
+        if ((rc = launch_poa_dataflow(e, A, d_work, work_ints, d_edge, d_cflag32, s)) != TSTA_OK) return rc;
+        hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
+        e->n_launches = 3;
+        e->poa_status = reinterpret_cast<unsigned*>(d_work + 1);
+        return e->check(hipGetLastError(), "poa_fill launch");
+    }
+    e->poa_status = nullptr;
     for (int d = 0; d < nchunks + nrb - 1; ++d) {            // tile anti-diagonals: q + rb = d
         const int q_lo = std::max(0, d - nrb + 1), q_hi = std::min(nchunks - 1, d);
         A.d = d; A.q_lo = q_lo;
@@ -742,6 +768,7 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
             return rc;
     }
     if ((rc = e->check(hipStreamSynchronize(s), "poa_fill sync"))) return rc;
+    if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     if (best_sink) *best_sink = h_res[0];
     return poa_reference_warning(e, p, V, seq, n, h_res[8]);
 }
@@ -777,6 +804,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
         return rc;
+    if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     const int ns = h_out[0];
     if (ns < 0 || (size_t)ns > cap) { e->set_error("walker returned %d steps", ns); return TSTA_ERR_INTERNAL; }
     tsta_poa_step* out = (tsta_poa_step*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(tsta_poa_step));

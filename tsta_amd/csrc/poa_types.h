@@ -34,6 +34,17 @@ struct PoaArgs {
 };
 
 
+// poa_dataflow.hip: the single-launch fill (tiles as tickets, solver + emitter waves)
+struct PoaDfArgs {
+    PoaArgs A;
+    unsigned* ticket; unsigned* status;
+    int* prog;                           // [nchunks]: row-blocks completed in chunk q
+    const int* tile_first; const int* tile_qlo; int n_d, n_tiles;   // anti-diagonal d = tiles tile_first[d] .. : chunks tile_qlo[d] ...
+    int* edge;                           // [V][nchunks+1]: H(r, last column of chunk q-1), i.e. the column left of chunk q
+    int* cflag32;                        // [V][nchunks+1]: as PoaArgs::cflag, one int each (sc1 dword hand-off)
+};
+int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_edge, int* d_cflag32, hipStream_t s);
+
 void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
 void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
 
