@@ -53,7 +53,7 @@ __device__ __forceinline__ void wait_progress(const int* word, int need, unsigne
         const int far = (need - cur) >> 7;                      // 64-step blocks take >= 12 us: 3.4 us of sleep per 128 steps is safe
         if (far > 0) { for (int i = 0; i < min(far, 32); ++i) __builtin_amdgcn_s_sleep(127); }
         else __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 20)) { if (lane == 0) atomicOr(status, 1u); break; }
+        if (++spins > (1 << 17)) { if (lane == 0) atomicOr(status, 1u); break; }      // far: ~14 s; near: ~0.1 s
         // once any wave has given up, nobody waits any more: the launch drains quickly
         if ((spins & 255) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }

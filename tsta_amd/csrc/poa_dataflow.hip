@@ -34,14 +34,15 @@ namespace tsta {
 constexpr int kDfKC = 2;                 // columns per lane
 constexpr int kDfCW = 64 * kDfKC;        // columns per tile
 
-// what the solver leaves for the emitters, per lane and row
-struct __align__(16) DfRec {
+// what the solver leaves for the emitters, per lane and row: 7 dwords, kept field-major in LDS (rec[field][row][lane]:
+// every access is 64 consecutive dwords, conflict-free; 56 KB for 32 rows)
+struct DfRec {
     int hs0, hs1;                        // H of the lane's two columns
     int es0, es1;                        // Eagg
     int fl0, fl1;                        // F
     int meta;                            // per column (16 bits each): jq | je(7 bits, bit 6 = "opened") << 6 | (bq==H) << 13 | (be==H) << 14 | open-flag << 15
-    int pad;
 };
+enum { F_HS0, F_HS1, F_ES0, F_ES1, F_FL0, F_FL1, F_META, F_COUNT };
 
 __device__ __forceinline__ int df_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
     int spins = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }
+        if (++spins > (1 << 18)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~30 ms
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
@@ -60,25 +61,26 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
 __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
 {
     const PoaArgs& A = P.A;
-    __shared__ DfRec rec[kRB][64];                       // 64 KB
+    __shared__ int rec[F_COUNT][kRB][64];                // 56 KB
     __shared__ int row_edge[kRB];                        // H(row, cbase): the column left of the tile
     __shared__ int row_h0[kRB];                          // chunk 0: H(row, 0)
     __shared__ int produced;                             // rows of this tile the solver has finished
-    __shared__ int ticket_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
     const int aK = kDfKC * E;
     const int ncar = A.nchunks + 1;
     const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
 
-    for (;;) {
-        if (threadIdx.x == 0) { ticket_s = (int)atomicAdd(P.ticket, 1u); produced = 0; }
-        __syncthreads();
-        const int t = ticket_s;
-        if (t >= P.n_tiles) return;
+    // Tiles are dealt statically: workgroup b runs tiles b, b + G, b + 2G, ... of the d-major order (G = gridDim.x, all
+    // resident).  The lowest unfinished tile always has finished producers and a workgroup that has nothing lower left to
+    // do, so the waits below always end.  (No ticket atomics and no barrier at the top of a tile.)
+    if (threadIdx.x == 0) produced = 0;
+    __syncthreads();
+    int rows_base = 0;                                   // rows this workgroup's solver has produced in earlier tiles
+    for (int t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
         int lo = 0, hi = P.n_d - 1;                      // d = last anti-diagonal whose first tile is <= t
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P.tile_first[mid] <= t) lo = mid; else hi = mid - 1; }
-        const int d = lo, q = P.tile_qlo[d] + (t - P.tile_first[d]), rb = d - q;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (__builtin_amdgcn_readfirstlane(P.tile_first[mid]) <= t) lo = mid; else hi = mid - 1; }
+        const int d = lo, q = __builtin_amdgcn_readfirstlane(P.tile_qlo[d] + (t - P.tile_first[d])), rb = d - q;
         const int r0 = rb * kRB, r1 = min(A.V, r0 + kRB), nrows = r1 - r0;
         const int cbase = q * kDfCW, c0 = cbase + lane * kDfKC;
 
@@ -153,10 +155,8 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                     } else if (p >= r0 && p < r1) {
                         // a row finished earlier in this tile: its record
                         const int ip = p - r0;
-                        const DfRec& R = rec[ip][lane];
-                        hv[1] = R.hs0; hv[2] = R.hs1; ev[0] = R.es0; ev[1] = R.es1;
-                        const int left = (lane > 0) ? rec[ip][lane - 1].hs1 : row_edge[ip];
-                        hv[0] = left;
+                        hv[1] = rec[F_HS0][ip][lane]; hv[2] = rec[F_HS1][ip][lane]; ev[0] = rec[F_ES0][ip][lane]; ev[1] = rec[F_ES1][ip][lane];
+                        hv[0] = (lane > 0) ? rec[F_HS1][ip][lane - 1] : row_edge[ip];
                     } else {
                         // a row of an earlier row-block (published before this tile started) or the virtual init row
                         const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
@@ -218,12 +218,11 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 {
                     const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
                     const unsigned m1 = (unsigned)jq[1] | ((unsigned)je[1] << 6) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
-                    DfRec R;
-                    R.hs0 = hs[0]; R.hs1 = hs[1]; R.es0 = be[0]; R.es1 = be[1]; R.fl0 = fl[0]; R.fl1 = fl[1]; R.meta = (int)(m0 | (m1 << 16)); R.pad = 0;
-                    rec[i][lane] = R;
+                    rec[F_HS0][i][lane] = hs[0]; rec[F_HS1][i][lane] = hs[1]; rec[F_ES0][i][lane] = be[0]; rec[F_ES1][i][lane] = be[1];
+                    rec[F_FL0][i][lane] = fl[0]; rec[F_FL1][i][lane] = fl[1]; rec[F_META][i][lane] = (int)(m0 | (m1 << 16));
                     if (lane == 0) { row_edge[i] = my_edge; row_h0[i] = h0; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is in LDS before the counter says so
-                    if (lane == 0) __hip_atomic_store(&produced, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
                 prev_r = r; h0_prev = h0;
@@ -241,9 +240,11 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
         } else {
             // ================================================================ emitters: rows i = wave-1, wave+2, ...
             for (int i = wave - 1; i < nrows; i += 3) {
-                if (!lds_wait_gt(&produced, i, P.status, lane)) break;
+                if (!lds_wait_gt(&produced, rows_base + i, P.status, lane)) break;
                 const int r = r0 + i;
-                const DfRec R = rec[i][lane];
+                DfRec R;
+                R.hs0 = rec[F_HS0][i][lane]; R.hs1 = rec[F_HS1][i][lane]; R.es0 = rec[F_ES0][i][lane]; R.es1 = rec[F_ES1][i][lane];
+                R.fl0 = rec[F_FL0][i][lane]; R.fl1 = rec[F_FL1][i][lane]; R.meta = rec[F_META][i][lane];
                 const int myslot = __builtin_amdgcn_readlane(slot_l, i);
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
                 int* Hr = A.Hrow + (size_t)myslot * A.pitch;
@@ -280,10 +281,12 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_h0[i]);                       // H(r, 0)
             }
         }
-        // every wave's stores have left before the tile is published
+        // every wave's stores have left before the tile is published; the emitters are done with the records before the
+        // solver overwrites them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store((GlobalI32*)(P.prog + q), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rows_base += nrows;
     }
 }
 
@@ -312,7 +315,7 @@ int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_in
     P.ticket = reinterpret_cast<unsigned*>(d_work); P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
     P.tile_first = d_work + head; P.tile_qlo = d_work + head + D + 1; P.n_d = D; P.n_tiles = (int)total;
     P.edge = d_edge; P.cflag32 = d_cflag32;
-    const int blocks = (int)std::min<int64_t>(total, e->n_cu);               // one workgroup per CU (65 KB of LDS each)
+    const int blocks = (int)std::min<int64_t>(total, e->n_cu);               // one workgroup per CU
     hipLaunchKernelGGL(poa_dataflow_kernel, dim3(blocks), dim3(256), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");
 }
