@@ -5,13 +5,13 @@
 // the chain of its rows, V x (time per row), and K4 spends ~0.9 us per row: one wave does everything a row needs (~460
 // instructions at the single-wave issue rate) and every tile anti-diagonal is a kernel launch.  Two things change here:
 //
-//  1. Dataflow instead of launches.  The tiles (32 consecutive nodes x 128 columns) are tickets, enumerated in the order the
-//     launch pipeline would run them (anti-diagonal d = chunk q + row-block rb, then q).  A workgroup takes a ticket, waits
-//     until its two producers have published — the tile above (prog[q] >= rb) and the tile on the left (prog[q-1] >= rb+1);
-//     both hold earlier tickets, so no deadlock whatever the number of resident workgroups — and publishes prog[q] = rb + 1.
-//     What crosses tiles goes through sc1 stores / loads (handoff.h): the H / Eagg rows of the nodes, the per-row F carry,
-//     open flag and H at the chunk's right edge (edge[]: kept per (row, chunk), so a recycled row slot is only ever read
-//     and rewritten inside ONE chunk's chain of tiles).
+//  1. One workgroup per chunk of 128 columns instead of one launch per tile anti-diagonal.  Workgroup q sweeps ALL the
+//     nodes of its chunk, 32 at a time; before each block of 32 it waits until the workgroup on its left has published that
+//     block (prog[q-1] > block), then publishes its own.  A workgroup waits only for its left neighbour and all of them are
+//     resident (<= 128 chunks), so the waits always end.  What crosses chunks goes through sc1 stores / loads (handoff.h):
+//     per row the F carry, the open flag and H at the chunk's right edge.  The chain of rows — the critical path — never
+//     leaves the workgroup: the backbone predecessor stays in the solver's registers from one block to the next, other
+//     predecessors come from the block's LDS records or (earlier blocks) from the H / Eagg rows this same workgroup stored.
 //  2. Solver + emitters.  Wave 0 of the workgroup (the solver) runs only what the NEXT row needs: predecessor maxima, the
 //     max-plus scan of F, final H / Eagg / F.  It leaves 7 dwords per lane and row in an LDS record; waves 1-3 (emitters, rows
 //     i = e mod 3) turn records into the reference's three trace codes (c-t-simd.c:485-506, 521-538, 564-565) and do all the
@@ -32,16 +32,15 @@
 namespace tsta {
 
 constexpr int kDfKC = 2;                 // columns per lane
-constexpr int kDfCW = 64 * kDfKC;        // columns per tile
+constexpr int kDfCW = 64 * kDfKC;        // columns per chunk
+constexpr int kDfRB = 32;                // nodes per block
+constexpr int kDfRing = 2 * kDfRB;       // rows whose records stay in LDS: this block and the one before (7 x 64 x 64 ints = 112 KB)
 
-// what the solver leaves for the emitters, per lane and row: 7 dwords, kept field-major in LDS (rec[field][row][lane]:
-// every access is 64 consecutive dwords, conflict-free; 56 KB for 32 rows)
-struct DfRec {
-    int hs0, hs1;                        // H of the lane's two columns
-    int es0, es1;                        // Eagg
-    int fl0, fl1;                        // F
-    int meta;                            // per column (16 bits each): jq | je(7 bits, bit 6 = "opened") << 6 | (bq==H) << 13 | (be==H) << 14 | open-flag << 15
-};
+// What the solver leaves per lane and row, field-major in LDS (rec[field][row][lane]: every access is 64 consecutive
+// dwords, conflict-free).  A BACKBONE row (one predecessor = the row before it, not the first row of a block) gets only
+// H, Eagg and F: everything else a trace code needs, the emitter recomputes from the record of the row above.  Any other
+// row also gets META: per column (16 bits each) jq | je(7 bits, bit 6 = "opened") << 6 | (bq==H) << 13 | (be==H) << 14 |
+// F-open flag << 15.
 enum { F_HS0, F_HS1, F_ES0, F_ES1, F_FL0, F_FL1, F_META, F_COUNT };
 
 __device__ __forceinline__ int df_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
@@ -58,176 +57,260 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
     return true;
 }
 
+// F of one row given the column maxima a[k] = max(diagonal, vertical-gap) candidates: local pass with no carry-in, max-plus
+// inclusive scan over the 64 lanes (DPP, VALU only), fix-up pass with the true carry (poa_fill.hip has the derivation).
+// Out: H, F per column, the carry leaving the chunk, per column whether F(c+1) opens from H(c).
+__device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, int lane, int E, int O, int aK, int w15, int w31,
+                                            int (&hs)[kDfKC], int (&fl)[kDfKC], int (&opn_next)[kDfKC], int& xout)
+{
+    int fbar = kNeg;
+#pragma unroll
+    for (int k = 0; k < kDfKC; ++k) {
+        const int f = fbar + E;
+        const int h = max(a[k], f);
+        fbar = max(f, h + O);
+    }
+    int v = fbar;
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false) + aK);
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false) + 2 * aK);
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false) + 4 * aK);
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false) + 8 * aK);
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false) + w15);
+    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
+    const int prev = df_shr1(kNeg, v);
+    fbar = max(prev, xin_row + lane * aK);
+    xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);
+#pragma unroll
+    for (int k = 0; k < kDfKC; ++k) {
+        const int f = fbar + E;
+        const int h = max(a[k], f);
+        hs[k] = h; fl[k] = f;
+        const int g = h + O;
+        opn_next[k] = (g >= f) ? 1 : 0;                  // F(c+1) == H(c)+O+E  <=>  H(c)+O >= F(c)
+        fbar = max(f, g);
+    }
+}
+
 __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
 {
     const PoaArgs& A = P.A;
-    __shared__ int rec[F_COUNT][kRB][64];                // 56 KB
-    __shared__ int row_edge[kRB];                        // H(row, cbase): the column left of the tile
-    __shared__ int row_h0[kRB];                          // chunk 0: H(row, 0)
-    __shared__ int produced;                             // rows of this tile the solver has finished
+    __shared__ int rec[F_COUNT][kDfRing][64];            // 112 KB, row r in slot r % 64
+    __shared__ int row_edge[kDfRing];                    // H(row, cbase): the column left of the chunk
+    __shared__ int row_h0[kDfRing];                      // chunk 0: H(row, 0)
+    __shared__ int row_flag[kDfRing];                    // "F of the chunk's first column opens" of each row
+    __shared__ int row_kind[kDfRing];                    // 1: backbone record (no META), 0: full record
+    __shared__ int produced;                             // rows the solver has finished since the kernel began
+    __shared__ int blk_done[4];                          // waves (of 4) that have finished block b, slot b & 3
+    __shared__ int blk_pub;                              // blocks published (all four waves done, stores drained)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
     const int aK = kDfKC * E;
     const int ncar = A.nchunks + 1;
     const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
 
-    // Tiles are dealt statically: workgroup b runs tiles b, b + G, b + 2G, ... of the d-major order (G = gridDim.x, all
-    // resident).  The lowest unfinished tile always has finished producers and a workgroup that has nothing lower left to
-    // do, so the waits below always end.  (No ticket atomics and no barrier at the top of a tile.)
-    if (threadIdx.x == 0) produced = 0;
+    if (threadIdx.x == 0) { produced = 0; blk_pub = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
     __syncthreads();
-    int rows_base = 0;                                   // rows this workgroup's solver has produced in earlier tiles
-    for (int t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
-        int lo = 0, hi = P.n_d - 1;                      // d = last anti-diagonal whose first tile is <= t
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (__builtin_amdgcn_readfirstlane(P.tile_first[mid]) <= t) lo = mid; else hi = mid - 1; }
-        const int d = lo, q = __builtin_amdgcn_readfirstlane(P.tile_qlo[d] + (t - P.tile_first[d])), rb = d - q;
-        const int r0 = rb * kRB, r1 = min(A.V, r0 + kRB), nrows = r1 - r0;
-        const int cbase = q * kDfCW, c0 = cbase + lane * kDfKC;
-
-        int sch[kDfKC];
+    const int q = blockIdx.x;                            // this workgroup's chunk
+    const int cbase = q * kDfCW, c0 = cbase + lane * kDfKC;
+    int sch[kDfKC];
 #pragma unroll
-        for (int k = 0; k < kDfKC; ++k) sch[k] = (c0 + k < n) ? (int)A.seq[c0 + k] : -1;
+    for (int k = 0; k < kDfKC; ++k) sch[k] = (c0 + k < n) ? (int)A.seq[c0 + k] : -1;
+    int rows_base = 0;                                   // rows the solver has produced in earlier blocks
+    // solver state that lives across blocks: the row just finished (the backbone predecessor of the next one)
+    int hs_prev[kDfKC] = {0, 0}, es_prev[kDfKC] = {0, 0}, prev_r = -2, h0_prev = 0, edge_prev = 0;
+    const int nblocks = (A.V + kDfRB - 1) / kDfRB;
+    // Solver only: the DAG metadata of a block's rows (one row per lane: offset / number of predecessors, the first four of
+    // them with their row slots) is loaded one block AHEAD, and so is what the chunk on the left handed over (F carry,
+    // open flag, edge H) when it has already published that block — the usual case once the chunks have spread out.
+    // None of these loads then sits on the chain of rows.
+    struct Meta { int poff, np, pr[4], ps[4]; };
+    auto load_meta = [&](int row0, int count) -> Meta {
+        Meta m; m.poff = 0; m.np = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { m.pr[x] = -1; m.ps[x] = 0; }
+        if (lane < count) {
+            m.poff = A.pred_off[row0 + lane];
+            m.np = A.pred_off[row0 + lane + 1] - m.poff;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) if (x < m.np) { m.pr[x] = A.pred[m.poff + x]; m.ps[x] = A.pred_slot[m.poff + x]; }
+        }
+        return m;
+    };
+    struct Left { int xin, flag, edge; };
+    auto load_left = [&](int row0, int count) -> Left {
+        Left l; l.xin = 0; l.flag = 1; l.edge = 0;
+        if (q > 0 && lane < count) {
+            l.xin = load_sc1_int(&A.carry[(size_t)(row0 + lane) * ncar + q]);
+            l.flag = load_sc1_int(&P.cflag32[(size_t)(row0 + lane) * ncar + q]);
+            l.edge = load_sc1_int(&P.edge[(size_t)(row0 + lane) * ncar + q]);
+        }
+        return l;
+    };
+    Meta meta_next; Left left_next; bool have_left_next = false;
+    if (wave == 0) meta_next = load_meta(0, min(A.V, kDfRB));
+    for (int rb = 0; rb < nblocks; ++rb) {
+        const int r0 = rb * kDfRB, r1 = min(A.V, r0 + kDfRB), nrows = r1 - r0;
+        const int s0 = r0 & (kDfRing - 1);               // ring slot of the block's first row
+        const int ring_lo = max(0, r0 - kDfRB);          // oldest row whose record is still in LDS
         int slot_l = 0, base_l = 0;
         if (lane < nrows) { slot_l = A.slot[r0 + lane]; base_l = A.base[r0 + lane]; }
 
         if (wave == 0) {
             // ================================================================ solver
-            if (rb > 0) wait_progress(P.prog + q, rb, P.status, lane);                  // the tile above (and, by induction, all above it)
-            if (q > 0)  wait_progress(P.prog + q - 1, rb + 1, P.status, lane);          // the tile on the left
-            int xin_l = 0, flag_l = 1, edge_l = 0;
-            if (q > 0 && lane < nrows) {
-                xin_l = load_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar + q]);
-                flag_l = load_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar + q]);
-                edge_l = load_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar + q]);
+            const Meta mt = meta_next;                        // loaded during the previous block
+            const int poff_l = mt.poff, np_l = mt.np, pfirst_l = mt.pr[0], pfslot_l = mt.ps[0];
+            // rows whose only predecessor is the row before them (the first row of a block: the row the previous block ended with)
+            const unsigned long long bb_mask = __ballot(lane < nrows && np_l == 1 && pfirst_l == r0 + lane - 1 && (lane > 0 || prev_r == r0 - 1));
+            // block rb-2 is complete (all four waves, stores drained): its ring half may be overwritten, and every row older than
+            // the ring can be read back from the H / Eagg rows
+            if (rb >= 2) lds_wait_gt(&blk_pub, rb - 2, P.status, lane);
+            Left lf = left_next;
+            if (!have_left_next) {
+                if (q > 0) wait_progress(P.prog + q - 1, rb + 1, P.status, lane);       // the chunk on the left has published this block
+                lf = load_left(r0, nrows);
             }
-            int poff_l = 0, np_l = 0, pfirst_l = -1, pfslot_l = 0;
-            if (lane < nrows) {
-                poff_l = A.pred_off[r0 + lane];
-                np_l = A.pred_off[r0 + lane + 1] - poff_l;
-                if (np_l > 0) { pfirst_l = A.pred[poff_l]; pfslot_l = A.pred_slot[poff_l]; }
+            const int xin_l = lf.xin, flag_l = lf.flag, edge_l = lf.edge;
+            // the next block's share, while this one is computed
+            if (rb + 1 < nblocks) {
+                const int nr0 = r0 + kDfRB, ncnt = min(A.V, nr0 + kDfRB) - nr0;
+                meta_next = load_meta(nr0, ncnt);
+                have_left_next = (q == 0) || progress_reached(P.prog + q - 1, rb + 2);
+                if (have_left_next) left_next = load_left(nr0, ncnt);
             }
             int cout_l = 0, fout_l = 0, eout_l = 0, spread_l = 0;
-            int hs_prev[kDfKC] = {0, 0}, es_prev[kDfKC] = {0, 0}, prev_r = -2, h0_prev = 0;
 
             for (int r = r0; r < r1; ++r) {
                 const int i = r - r0;
-                const int p0 = __builtin_amdgcn_readlane(poff_l, i), np = __builtin_amdgcn_readlane(np_l, i);
-                const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i), pfslot = __builtin_amdgcn_readlane(pfslot_l, i);
-                const bool is_src = (np == 0);               // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
-                int h0 = 0, xin_row, flag_row;
-                if (q == 0) {                                // first column (c-t-simd.c:187,194-200)
-                    if (is_src) h0 = OE;
-                    else {
-                        h0 = kNeg;
-                        for (int j = 0; j < np; ++j) {
-                            const int p = (j == 0) ? pfirst : A.pred[p0 + j];
-                            const int ps = (j == 0) ? pfslot : A.pred_slot[p0 + j];
-                            int hp;
-                            if (p == prev_r) hp = h0_prev;
-                            else if (p >= r0) hp = row_h0[p - r0];
-                            else hp = load_sc1_int(&A.Hrow[(size_t)ps * A.pitch + 3]);
-                            h0 = max(h0, hp);
+                const bool backbone = (bb_mask >> i) & 1ull;
+                int sc[kDfKC], a[kDfKC], bq[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
+#pragma unroll
+                for (int k = 0; k < kDfKC; ++k) sc[k] = (sch[k] == bs) ? M : X;
+                int h0 = 0, xin_row, flag_row, my_edge, xout;
+                if (backbone) {
+                    // ---------------- straight line: H / Eagg of the row above are in registers, its column on the left of
+                    // this lane comes by one DPP shift
+                    if (q == 0) { h0 = h0_prev + E; xin_row = h0 + O; flag_row = 1; my_edge = h0; }   // c-t-simd.c:187,194-200
+                    else { xin_row = __builtin_amdgcn_readlane(xin_l, i); flag_row = __builtin_amdgcn_readlane(flag_l, i); my_edge = __builtin_amdgcn_readlane(edge_l, i); }
+                    const int hv0 = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
+                    bq[0] = hv0 + sc[0]; bq[1] = hs_prev[0] + sc[1];
+                    be[0] = max(es_prev[0] + E, hs_prev[0] + OE);                 // c-t-simd.c:524-528
+                    be[1] = max(es_prev[1] + E, hs_prev[1] + OE);
+                    a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
+                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next, xout);
+                    {
+                        const int si = s0 + i;
+                        rec[F_HS0][si][lane] = hs[0]; rec[F_HS1][si][lane] = hs[1]; rec[F_ES0][si][lane] = be[0]; rec[F_ES1][si][lane] = be[1];
+                        rec[F_FL0][si][lane] = fl[0]; rec[F_FL1][si][lane] = fl[1];
+                        if (i == 0) {                        // the row above lives in the previous block's records: full record instead
+                            const int opn0 = df_shr1(flag_row, opn_next[1]);
+                            const unsigned m0 = ((be[0] == hs_prev[0] + OE) ? (64u << 6) : 0u) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
+                            const unsigned m1 = ((be[1] == hs_prev[1] + OE) ? (64u << 6) : 0u) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
+                            rec[F_META][si][lane] = (int)(m0 | (m1 << 16));
                         }
-                        h0 += E;
+                        if (lane == 0) { row_edge[si] = my_edge; row_h0[si] = h0; row_flag[si] = flag_row; row_kind[si] = (i == 0) ? 0 : 1; }
                     }
-                    xin_row = h0 + O; flag_row = 1;          // F(r,0) = -inf: the first F is an open
                 } else {
-                    xin_row = __builtin_amdgcn_readlane(xin_l, i);
-                    flag_row = __builtin_amdgcn_readlane(flag_l, i);
-                }
-                const int my_edge = (q == 0) ? h0 : __builtin_amdgcn_readlane(edge_l, i);     // H(r, cbase)
-
-                int bq[kDfKC], jq[kDfKC], be[kDfKC], je[kDfKC], sc[kDfKC];
-#pragma unroll
-                for (int k = 0; k < kDfKC; ++k) { sc[k] = (sch[k] == bs) ? M : X; bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0; }
-                const int npp = is_src ? 1 : np;
-                int hmx[kDfKC] = {kNeg, kNeg}, hmn[kDfKC] = {-kNeg, -kNeg};
-                for (int j = 0; j < npp; ++j) {
-                    const int p = is_src ? A.V : ((j == 0) ? pfirst : A.pred[p0 + j]);
-                    const int ps = is_src ? 0 : ((j == 0) ? pfslot : A.pred_slot[p0 + j]);
-                    int hv[kDfKC + 1], ev[kDfKC];
-                    if (p == prev_r) {
-                        // the row just finished: registers + one lane shift
-                        const int edge = (q == 0) ? h0_prev : __builtin_amdgcn_readlane(edge_l, i - 1);
-                        hv[0] = df_shr1(edge, hs_prev[kDfKC - 1]);
-                        hv[1] = hs_prev[0]; hv[2] = hs_prev[1]; ev[0] = es_prev[0]; ev[1] = es_prev[1];
-                    } else if (p >= r0 && p < r1) {
-                        // a row finished earlier in this tile: its record
-                        const int ip = p - r0;
-                        hv[1] = rec[F_HS0][ip][lane]; hv[2] = rec[F_HS1][ip][lane]; ev[0] = rec[F_ES0][ip][lane]; ev[1] = rec[F_ES1][ip][lane];
-                        hv[0] = (lane > 0) ? rec[F_HS1][ip][lane - 1] : row_edge[ip];
+                    // ---------------- any other row: virtual init predecessor, several predecessors, a predecessor further back
+                    const int p0 = __builtin_amdgcn_readlane(poff_l, i), np = __builtin_amdgcn_readlane(np_l, i);
+                    const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i), pfslot = __builtin_amdgcn_readlane(pfslot_l, i);
+                    // predecessor j of this row and its row slot: the first four travel in lanes, the rest is read from memory
+                    auto pred_of = [&](int j, int& p, int& ps) {
+                        if (j == 0) { p = pfirst; ps = pfslot; }
+                        else if (j == 1) { p = __builtin_amdgcn_readlane(mt.pr[1], i); ps = __builtin_amdgcn_readlane(mt.ps[1], i); }
+                        else if (j == 2) { p = __builtin_amdgcn_readlane(mt.pr[2], i); ps = __builtin_amdgcn_readlane(mt.ps[2], i); }
+                        else if (j == 3) { p = __builtin_amdgcn_readlane(mt.pr[3], i); ps = __builtin_amdgcn_readlane(mt.ps[3], i); }
+                        else { p = A.pred[p0 + j]; ps = A.pred_slot[p0 + j]; }
+                    };
+                    const bool is_src = (np == 0);           // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
+                    if (q == 0) {                            // first column (c-t-simd.c:187,194-200)
+                        if (is_src) h0 = OE;
+                        else {
+                            h0 = kNeg;
+                            for (int j = 0; j < np; ++j) {
+                                int p, ps;
+                                pred_of(j, p, ps);
+                                int hp;
+                                if (p == prev_r) hp = h0_prev;
+                                else if (p >= ring_lo) hp = row_h0[p & (kDfRing - 1)];
+                                else hp = load_sc1_int(&A.Hrow[(size_t)ps * A.pitch + 3]);
+                                h0 = max(h0, hp);
+                            }
+                            h0 += E;
+                        }
+                        xin_row = h0 + O; flag_row = 1; my_edge = h0;   // F(r,0) = -inf: the first F is an open
                     } else {
-                        // a row of an earlier row-block (published before this tile started) or the virtual init row
-                        const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
-                        const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
-                        // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
-                        hv[0] = (lane == 0 && q > 0 && !is_src) ? load_sc1_int(&P.edge[(size_t)p * ncar + q]) : load_sc1_int(Hp);
-                        const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
-                        const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
-                        hv[1] = ha.x; hv[2] = ha.y; ev[0] = ea.x; ev[1] = ea.y;
+                        xin_row = __builtin_amdgcn_readlane(xin_l, i); flag_row = __builtin_amdgcn_readlane(flag_l, i);
+                        my_edge = __builtin_amdgcn_readlane(edge_l, i);
                     }
+                    int jq[kDfKC], je[kDfKC];
 #pragma unroll
-                    for (int k = 0; k < kDfKC; ++k) {
-                        const int qv = hv[k] + sc[k];                              // diagonal from H(p, c-1)
-                        if (qv > bq[k]) { bq[k] = qv; jq[k] = j; }                 // lowest predecessor index on ties
-                        const int eo = hv[k + 1] + OE, ex = ev[k] + E;             // c-t-simd.c:524-528
-                        const int ein = max(ex, eo);
-                        if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
-                        if (npp > 1) { hmx[k] = max(hmx[k], hv[k + 1]); hmn[k] = min(hmn[k], hv[k + 1]); }
+                    for (int k = 0; k < kDfKC; ++k) { bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0; }
+                    const int npp = is_src ? 1 : np;
+                    int hmx[kDfKC] = {kNeg, kNeg}, hmn[kDfKC] = {-kNeg, -kNeg};
+                    for (int j = 0; j < npp; ++j) {
+                        int p = A.V, ps = 0;
+                        if (!is_src) pred_of(j, p, ps);
+                        int hv[kDfKC + 1], ev[kDfKC];
+                        if (p == prev_r) {
+                            hv[0] = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
+                            hv[1] = hs_prev[0]; hv[2] = hs_prev[1]; ev[0] = es_prev[0]; ev[1] = es_prev[1];
+                        } else if (!is_src && p >= ring_lo) {
+                            // a row finished earlier in this block or in the previous one: its record
+                            const int ip = p & (kDfRing - 1);
+                            hv[1] = rec[F_HS0][ip][lane]; hv[2] = rec[F_HS1][ip][lane]; ev[0] = rec[F_ES0][ip][lane]; ev[1] = rec[F_ES1][ip][lane];
+                            hv[0] = (lane > 0) ? rec[F_HS1][ip][lane - 1] : row_edge[ip];
+                        } else {
+                            // a row older than the ring (stored by this workgroup's emitters; its block was published before this one began)
+                            // or the virtual init row
+                            const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
+                            const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
+                            // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
+                            hv[0] = (lane == 0 && q > 0 && !is_src) ? load_sc1_int(&P.edge[(size_t)p * ncar + q]) : load_sc1_int(Hp);
+                            const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
+                            const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
+                            hv[1] = ha.x; hv[2] = ha.y; ev[0] = ea.x; ev[1] = ea.y;
+                        }
+#pragma unroll
+                        for (int k = 0; k < kDfKC; ++k) {
+                            const int qv = hv[k] + sc[k];                          // diagonal from H(p, c-1)
+                            if (qv > bq[k]) { bq[k] = qv; jq[k] = j; }             // lowest predecessor index on ties
+                            const int eo = hv[k + 1] + OE, ex = ev[k] + E;         // c-t-simd.c:524-528
+                            const int ein = max(ex, eo);
+                            if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
+                            if (npp > 1) { hmx[k] = max(hmx[k], hv[k + 1]); hmn[k] = min(hmn[k], hv[k + 1]); }
+                        }
+                    }
+                    if (npp > 1) {
+#pragma unroll
+                        for (int k = 0; k < kDfKC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
+                    }
+                    a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
+                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next, xout);
+                    {
+                        const int opn0 = df_shr1(flag_row, opn_next[1]);           // F-open flag of the lane's first column: from the left
+                        const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
+                        const unsigned m1 = (unsigned)jq[1] | ((unsigned)je[1] << 6) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
+                        const int si = s0 + i;
+                        rec[F_HS0][si][lane] = hs[0]; rec[F_HS1][si][lane] = hs[1]; rec[F_ES0][si][lane] = be[0]; rec[F_ES1][si][lane] = be[1];
+                        rec[F_FL0][si][lane] = fl[0]; rec[F_FL1][si][lane] = fl[1]; rec[F_META][si][lane] = (int)(m0 | (m1 << 16));
+                        if (lane == 0) { row_edge[si] = my_edge; row_h0[si] = h0; row_flag[si] = flag_row; row_kind[si] = 0; }
                     }
                 }
-                if (npp > 1) {
-#pragma unroll
-                    for (int k = 0; k < kDfKC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
-                }
-                // ---- F: local pass with no carry-in, max-plus inclusive scan over the 64 lanes, fix-up pass (as poa_fill.hip)
-                int fbar = kNeg;
-#pragma unroll
-                for (int k = 0; k < kDfKC; ++k) {
-                    const int f = fbar + E;
-                    const int h = max(max(bq[k], be[k]), f);
-                    fbar = max(f, h + O);
-                }
-                int v = fbar;
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false) + aK);
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false) + 2 * aK);
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false) + 4 * aK);
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false) + 8 * aK);
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false) + w15);
-                v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
-                const int prev = df_shr1(kNeg, v);
-                const int xin = max(prev, xin_row + lane * aK);
-                const int xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);
-                fbar = xin;
-                int hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
-#pragma unroll
-                for (int k = 0; k < kDfKC; ++k) {
-                    const int f = fbar + E;
-                    const int h = max(max(bq[k], be[k]), f);
-                    hs[k] = h; fl[k] = f;
-                    const int g = h + O;
-                    opn_next[k] = (g >= f) ? 1 : 0;          // F(c+1) == H(c)+O+E  <=>  H(c)+O >= F(c)
-                    fbar = max(f, g);
-                }
-                const int opn0 = df_shr1(flag_row, opn_next[kDfKC - 1]);   // open flag of the lane's first column: from the left
-                const int flag_out = __builtin_amdgcn_readlane(opn_next[kDfKC - 1], 63);
-                const int edge_out = __builtin_amdgcn_readlane(hs[kDfKC - 1], 63);
-                if (lane == i) { cout_l = xout; fout_l = flag_out; eout_l = edge_out; }
-                // ---- the record for the emitters (and for later rows of this tile that have this row as a predecessor)
                 {
-                    const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
-                    const unsigned m1 = (unsigned)jq[1] | ((unsigned)je[1] << 6) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
-                    rec[F_HS0][i][lane] = hs[0]; rec[F_HS1][i][lane] = hs[1]; rec[F_ES0][i][lane] = be[0]; rec[F_ES1][i][lane] = be[1];
-                    rec[F_FL0][i][lane] = fl[0]; rec[F_FL1][i][lane] = fl[1]; rec[F_META][i][lane] = (int)(m0 | (m1 << 16));
-                    if (lane == 0) { row_edge[i] = my_edge; row_h0[i] = h0; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is in LDS before the counter says so
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the record is in LDS before the counter says so
                     if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                // what the chunk on the right needs of this row, gathered one row per lane
+                {
+                    const int flag_out = __builtin_amdgcn_readlane(opn_next[kDfKC - 1], 63);
+                    const int edge_out = __builtin_amdgcn_readlane(hs[kDfKC - 1], 63);
+                    if (lane == i) { cout_l = xout; fout_l = flag_out; eout_l = edge_out; }
+                }
                 hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
-                prev_r = r; h0_prev = h0;
+                prev_r = r; h0_prev = h0; edge_prev = my_edge;
             }
-            if (lane < nrows) {                               // what the tile on the right needs of these rows
+            if (lane < nrows) {
                 store_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar + q + 1], cout_l);
                 store_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar + q + 1], fout_l);
                 store_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar + q + 1], eout_l);
@@ -241,20 +324,36 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
             // ================================================================ emitters: rows i = wave-1, wave+2, ...
             for (int i = wave - 1; i < nrows; i += 3) {
                 if (!lds_wait_gt(&produced, rows_base + i, P.status, lane)) break;
-                const int r = r0 + i;
-                DfRec R;
-                R.hs0 = rec[F_HS0][i][lane]; R.hs1 = rec[F_HS1][i][lane]; R.es0 = rec[F_ES0][i][lane]; R.es1 = rec[F_ES1][i][lane];
-                R.fl0 = rec[F_FL0][i][lane]; R.fl1 = rec[F_FL1][i][lane]; R.meta = rec[F_META][i][lane];
+                const int r = r0 + i, si = s0 + i;
+                const int hs0 = rec[F_HS0][si][lane], hs1 = rec[F_HS1][si][lane], es0 = rec[F_ES0][si][lane], es1 = rec[F_ES1][si][lane];
+                const int fl0 = rec[F_FL0][si][lane], fl1 = rec[F_FL1][si][lane];
                 const int myslot = __builtin_amdgcn_readlane(slot_l, i);
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
+                unsigned meta;
+                if (row_kind[si]) {
+                    // backbone row: its single predecessor is row i-1 of this block; what the solver did not write is rebuilt
+                    // from that row's record (c-t-simd.c:485-506, 524-538, 564-565)
+                    const int ph0 = rec[F_HS0][si - 1][lane], ph1 = rec[F_HS1][si - 1][lane];
+                    const int phl = (lane > 0) ? rec[F_HS1][si - 1][lane - 1] : row_edge[si - 1];      // H(p, column left of this lane)
+                    const int bq0 = phl + ((sch[0] == bs) ? M : X), bq1 = ph0 + ((sch[1] == bs) ? M : X);
+                    const int eo0 = ph0 + OE, eo1 = ph1 + OE;
+                    // F-open flag of a column: H(c-1) + O >= F(c-1); the lane's first column looks at the lane on the left / the chunk edge
+                    const int opn0 = (lane > 0) ? ((rec[F_HS1][si][lane - 1] + O >= rec[F_FL1][si][lane - 1]) ? 1 : 0) : row_flag[si];
+                    const int opn1 = (hs0 + O >= fl0) ? 1 : 0;
+                    const unsigned m0 = ((es0 == eo0) ? (64u << 6) : 0u) | ((bq0 == hs0) ? (1u << 13) : 0u) | ((es0 == hs0) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
+                    const unsigned m1 = ((es1 == eo1) ? (64u << 6) : 0u) | ((bq1 == hs1) ? (1u << 13) : 0u) | ((es1 == hs1) ? (1u << 14) : 0u) | ((unsigned)opn1 << 15);
+                    meta = m0 | (m1 << 16);
+                } else {
+                    meta = (unsigned)rec[F_META][si][lane];
+                }
                 int* Hr = A.Hrow + (size_t)myslot * A.pitch;
                 int* Er = A.Erow + (size_t)myslot * A.pitch;
                 if (c0 < n) {
                     unsigned w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
                     for (int k = 0; k < kDfKC; ++k) {
-                        const int h = k ? R.hs1 : R.hs0, f = k ? R.fl1 : R.fl0, be = k ? R.es1 : R.es0;
-                        const int m = (int)(((unsigned)R.meta >> (16 * k)) & 0xffffu);
+                        const int h = k ? hs1 : hs0, f = k ? fl1 : fl0, be = k ? es1 : es0;
+                        const int m = (int)((meta >> (16 * k)) & 0xffffu);
                         const int jq = m & 63, je = (m >> 6) & 127;
                         const bool mt = (sch[k] == bs);
                         int code;                            // match > mismatch > E > F (c-t-simd.c:485-506)
@@ -269,54 +368,47 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         w2 |= (unsigned)(uint8_t)ecode << (8 * k);
                         w3 |= (unsigned)(uint8_t)fcode << (8 * k);
                     }
-                    store_sc1_int2(reinterpret_cast<int2*>(Hr + c0 + 4), R.hs0, R.hs1);          // H(r, c0+1..c0+2): read by later tiles of this launch
-                    store_sc1_int2(reinterpret_cast<int2*>(Er + c0), R.es0, R.es1);
+                    store_sc1_int2(reinterpret_cast<int2*>(Hr + c0 + 4), hs0, hs1);              // H(r, c0+1..c0+2): read by later blocks of this launch
+                    store_sc1_int2(reinterpret_cast<int2*>(Er + c0), es0, es1);
                     if (A.source) {                                                           // trace: read after the launch only
                         *reinterpret_cast<unsigned short*>(A.source + (size_t)r * A.tpitch + c0) = (unsigned short)w1;
                         *reinterpret_cast<unsigned short*>(A.esource + (size_t)r * A.tpitch + c0) = (unsigned short)w2;
                         *reinterpret_cast<unsigned short*>(A.fsource + (size_t)r * A.tpitch + c0) = (unsigned short)w3;
                     }
-                    if (c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? R.hs1 : R.hs0;     // owner of the last column
+                    if (c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;         // owner of the last column
                 }
-                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_h0[i]);                       // H(r, 0)
+                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_h0[si]);                      // H(r, 0)
             }
         }
-        // every wave's stores have left before the tile is published; the emitters are done with the records before the
-        // solver overwrites them
+        // No barrier: the solver runs on into the next block while the emitters finish this one.  Every wave, once ITS stores
+        // of the block have left, counts itself in; the fourth one publishes the block — to the chunk on the right (prog[q],
+        // sc1) and to this workgroup's solver (blk_pub: it may then recycle the block's ring half two blocks later).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store((GlobalI32*)(P.prog + q), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            const int before = __hip_atomic_fetch_add(&blk_done[rb & 3], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (before == 3) {
+                __hip_atomic_store(&blk_done[rb & 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store((GlobalI32*)(P.prog + q), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&blk_pub, rb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         rows_base += nrows;
     }
 }
 
-// Launches the dataflow fill (A complete, inputs uploaded, virtual init row written).  `work` = device ints for this call:
-// [0] ticket, [1] status, [16 .. 16+nchunks) progress per chunk, then the tile table; edge / cflag32 = [V][nchunks+1] ints.
+// Launches the fill (A complete, inputs uploaded, virtual init row written).  `work` = device ints for this call:
+// [1] status, [16 .. 16+nchunks) blocks of 32 nodes completed per chunk; edge / cflag32 = [V][nchunks+1] ints.
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_edge, int* d_cflag32, hipStream_t s)
 {
-    const int D = A.nchunks + A.nrb - 1;
-    std::vector<int> tab((size_t)2 * D + 1);
-    int64_t total = 0;
-    for (int d = 0; d < D; ++d) {
-        const int q_lo = std::max(0, d - A.nrb + 1), q_hi = std::min(A.nchunks - 1, d);
-        tab[(size_t)d] = (int)total; tab[(size_t)(D + 1 + d)] = q_lo;
-        total += q_hi - q_lo + 1;
-    }
-    tab[(size_t)D] = (int)total;
     const size_t head = 16 + (size_t)A.nchunks;
-    if (total > 0x7fffffff || head + tab.size() > work_ints) return TSTA_ERR_INTERNAL;
+    if (head > work_ints || A.nchunks > e->n_cu) return TSTA_ERR_INTERNAL;   // every workgroup must be resident: one per CU
     int rc;
-    if ((rc = e->check(hipMemsetAsync(d_work, 0, head * sizeof(int), s), "hipMemsetAsync(poa dataflow)")) ||
-        (rc = e->check(hipMemcpyAsync(d_work + head, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D tile table")) ||
-        (rc = e->check(hipStreamSynchronize(s), "poa dataflow upload")))         // `tab` lives on this stack frame
-        return rc;
+    if ((rc = e->check(hipMemsetAsync(d_work, 0, head * sizeof(int), s), "hipMemsetAsync(poa dataflow)"))) return rc;
     PoaDfArgs P;
     P.A = A;
-    P.ticket = reinterpret_cast<unsigned*>(d_work); P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
-    P.tile_first = d_work + head; P.tile_qlo = d_work + head + D + 1; P.n_d = D; P.n_tiles = (int)total;
+    P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
     P.edge = d_edge; P.cflag32 = d_cflag32;
-    const int blocks = (int)std::min<int64_t>(total, e->n_cu);               // one workgroup per CU
-    hipLaunchKernelGGL(poa_dataflow_kernel, dim3(blocks), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks), dim3(256), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");
 }
 

@@ -709,7 +709,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
 
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
-    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && memchr(seq, 'N', (size_t)n) == nullptr;
+    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && nchunks <= e->n_cu && memchr(seq, 'N', (size_t)n) == nullptr;
     e->timing_begin(s);
     hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
     int launches = 1;

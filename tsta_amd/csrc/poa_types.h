@@ -34,12 +34,11 @@ struct PoaArgs {
 };
 
 
-// poa_dataflow.hip: the single-launch fill (tiles as tickets, solver + emitter waves)
+// poa_dataflow.hip: the single-launch fill (one workgroup per 128-column chunk, solver + emitter waves)
 struct PoaDfArgs {
     PoaArgs A;
-    unsigned* ticket; unsigned* status;
-    int* prog;                           // [nchunks]: row-blocks completed in chunk q
-    const int* tile_first; const int* tile_qlo; int n_d, n_tiles;   // anti-diagonal d = tiles tile_first[d] .. : chunks tile_qlo[d] ...
+    unsigned* status;
+    int* prog;                           // [nchunks]: blocks of 64 nodes completed in chunk q
     int* edge;                           // [V][nchunks+1]: H(r, last column of chunk q-1), i.e. the column left of chunk q
     int* cflag32;                        // [V][nchunks+1]: as PoaArgs::cflag, one int each (sc1 dword hand-off)
 };
