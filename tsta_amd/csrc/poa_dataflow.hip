@@ -59,9 +59,10 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
 
 // F of one row given the column maxima a[k] = max(diagonal, vertical-gap) candidates: local pass with no carry-in, max-plus
 // inclusive scan over the 64 lanes (DPP, VALU only), fix-up pass with the true carry (poa_fill.hip has the derivation).
-// Out: H, F per column, the carry leaving the chunk, per column whether F(c+1) opens from H(c).
+// Out: H, F per column, per column whether F(c+1) opens from H(c).  (The carry leaving the chunk is max(F, H+O) of the last
+// column: the emitters take it from lane 63's record.)
 __device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, int lane, int E, int O, int aK, int w15, int w31,
-                                            int (&hs)[kDfKC], int (&fl)[kDfKC], int (&opn_next)[kDfKC], int& xout)
+                                            int (&hs)[kDfKC], int (&fl)[kDfKC], int (&opn_next)[kDfKC])
 {
     int fbar = kNeg;
 #pragma unroll
@@ -79,7 +80,6 @@ __device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, 
     v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
     const int prev = df_shr1(kNeg, v);
     fbar = max(prev, xin_row + lane * aK);
-    xout = max(__builtin_amdgcn_readlane(v, 63), xin_row + 64 * aK);
 #pragma unroll
     for (int k = 0; k < kDfKC; ++k) {
         const int f = fbar + E;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 have_left_next = (q == 0) || progress_reached(P.prog + q - 1, rb + 2);
                 if (have_left_next) left_next = load_left(nr0, ncnt);
             }
-            int cout_l = 0, fout_l = 0, eout_l = 0, spread_l = 0;
+            int spread_l = 0;
 
             for (int r = r0; r < r1; ++r) {
                 const int i = r - r0;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 int sc[kDfKC], a[kDfKC], bq[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
 #pragma unroll
                 for (int k = 0; k < kDfKC; ++k) sc[k] = (sch[k] == bs) ? M : X;
-                int h0 = 0, xin_row, flag_row, my_edge, xout;
+                int h0 = 0, xin_row, flag_row, my_edge;
                 if (backbone) {
                     // ---------------- straight line: H / Eagg of the row above are in registers, its column on the left of
                     // this lane comes by one DPP shift
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                     be[0] = max(es_prev[0] + E, hs_prev[0] + OE);                 // c-t-simd.c:524-528
                     be[1] = max(es_prev[1] + E, hs_prev[1] + OE);
                     a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next, xout);
+                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next);
                     {
                         const int si = s0 + i;
                         rec[F_HS0][si][lane] = hs[0]; rec[F_HS1][si][lane] = hs[1]; rec[F_ES0][si][lane] = be[0]; rec[F_ES1][si][lane] = be[1];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         for (int k = 0; k < kDfKC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
                     }
                     a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next, xout);
+                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next);
                     {
                         const int opn0 = df_shr1(flag_row, opn_next[1]);           // F-open flag of the lane's first column: from the left
                         const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
@@ -297,23 +297,13 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         if (lane == 0) { row_edge[si] = my_edge; row_h0[si] = h0; row_flag[si] = flag_row; row_kind[si] = 0; }
                     }
                 }
-                {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the record is in LDS before the counter says so
-                    if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                // what the chunk on the right needs of this row, gathered one row per lane
-                {
-                    const int flag_out = __builtin_amdgcn_readlane(opn_next[kDfKC - 1], 63);
-                    const int edge_out = __builtin_amdgcn_readlane(hs[kDfKC - 1], 63);
-                    if (lane == i) { cout_l = xout; fout_l = flag_out; eout_l = edge_out; }
-                }
+                // the counter follows the record: the LDS performs one wave's operations in issue order, so no wait is needed
+                // here (a workgroup-scope release fence would drain the seven writes first: ~150 cycles on the chain of rows);
+                // the wavefront-scope fence only keeps the compiler from reordering
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
                 prev_r = r; h0_prev = h0; edge_prev = my_edge;
-            }
-            if (lane < nrows) {
-                store_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar + q + 1], cout_l);
-                store_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar + q + 1], fout_l);
-                store_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar + q + 1], eout_l);
             }
             if (__ballot(spread_l > 0)) {
 #pragma unroll
@@ -378,6 +368,11 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                     if (c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;         // owner of the last column
                 }
                 if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_h0[si]);                      // H(r, 0)
+                if (lane == 63) {                             // what the chunk on the right needs of this row (c-t-simd.c: v0 / f0 carries)
+                    store_sc1_int(&A.carry[(size_t)r * ncar + q + 1], max(fl1, hs1 + O));          // Fbar leaving the chunk
+                    store_sc1_int(&P.cflag32[(size_t)r * ncar + q + 1], (hs1 + O >= fl1) ? 1 : 0);  // its first F opens from H
+                    store_sc1_int(&P.edge[(size_t)r * ncar + q + 1], hs1);                         // H at the chunk's right edge
+                }
             }
         }
         // No barrier: the solver runs on into the next block while the emitters finish this one.  Every wave, once ITS stores
