@@ -183,10 +183,9 @@ def config4(eng):
 if __name__ == "__main__":
     eng = tsta_amd.Engine(0)
     which = sys.argv[1:] or ["2", "3", "4"]
-    # The launch-per-tile pipelines (configs #3, #4, batched traceback) are measured BEFORE anything makes PyTorch
-    # initialise its HIP context in this process: once it has (a 16-byte torch.zeros on the GPU is enough), the
-    # overlapping launch sequences of tsta_psa_align_batch stop overlapping (72 -> 99 ms; 87 ms on one stream) - an
-    # effect of sharing the process with PyTorch, not of the engine; C callers and the CLIs never see it.
+    # (Round 1 measured the launch-per-tile pipelines before anything initialised PyTorch's HIP context: the four overlapping
+    # launch sequences of tsta_psa_align_batch stopped overlapping once the process had other streams.  Cause: hardware queues;
+    # the single-launch forms of round 2 do not depend on them.  The order is kept.)
     if "3" in which:
         print(json.dumps(config3(eng)), flush=True)
     if "5t" in which:
