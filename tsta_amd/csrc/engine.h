@@ -42,7 +42,7 @@ struct Engine {
 
     void set_error(const char* fmt, ...);
     int  check(hipError_t e, const char* what);
-    int  reserve(DevBuf& b, size_t bytes, const char* what);
+    int  reserve(DevBuf& b, size_t bytes, const char* what, bool growing = false);
     void timing_begin(hipStream_t s);
     void timing_end(hipStream_t s);
 };

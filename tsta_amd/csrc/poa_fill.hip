@@ -665,13 +665,13 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     }
     const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 8 + (size_t)V * 4 + (size_t)V * 2 + (size_t)n + 64;
     const size_t rows_bytes = (size_t)nslots * pitch * sizeof(int);
-    if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)")) ||
-        (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)")) ||
-        (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)")) ||
-        (rc = e->reserve(e->scratch, 3 * (size_t)V * (nchunks + 1) * 4 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)")) ||
-        (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)")))
+    if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)", true)) ||
+        (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)", true)) ||
+        (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)", true)) ||
+        (rc = e->reserve(e->scratch, 3 * (size_t)V * (nchunks + 1) * 4 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)", true)) ||
+        (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)", true)))
         return rc;
-    if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)"))) return rc;
+    if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)", true))) return rc;
 
     char* m = reinterpret_cast<char*>(e->in_meta.p);
     int* d_off = reinterpret_cast<int*>(m);
@@ -788,7 +788,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
     const size_t cap = (size_t)V + (size_t)n + 2;
-    if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)"))) return rc;
+    if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)", true))) return rc;
     PoaWalkArgs Wk;
     Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink;
     Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch;
