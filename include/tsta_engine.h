@@ -73,6 +73,8 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
  *   "align_ws_gb"      0 auto (default: tsta_psa_align_batch works in groups of <= 16 GB of trace on an engine's first call,
  *                      64 GB on the second, everything after that: device memory costs ~35 ms per GB to allocate) | cap in GB
+ *   "trace_lds"        1 (default): single-pair trace fill hands the bottom row of three of every four bands to the next band
+ *                      through LDS rings inside a workgroup (psa_trace_quad_kernel) | 0: every hand-off through memory
  *   "poa_dataflow"     1 (default): POA fill as one launch, tiles handed out as tickets, a solver wave + three emitter waves per
  *                      tile (poa_dataflow.hip; sequences <= 16384 without 'N') | 0: always one launch per tile anti-diagonal
  *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against

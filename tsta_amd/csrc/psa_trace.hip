@@ -137,6 +137,161 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
     }
 }
 
+// ---- the four bands of one workgroup handed to each other through LDS (psa_trace_quad_kernel below) -----------------------
+// A band's bottom row reaches the band below as one {H, Ebar} entry per column in an LDS ring, 16 columns at a time and
+// through the registers the memory hand-off uses: after every 16 steps lanes 48..63 of the capture registers (sh, se) hold
+// the 16 columns lane 63 finished last (t-79 .. t-64 after step t): one LDS store; the band below refills lanes 0..15 of its
+// top-row registers (th, te) with the 16 columns its next 16 steps consume: one LDS load.  Nothing is added to a step.
+// Flow control at the same moments: the reader waits until the writer's `done` word covers its 16 columns (writer 80 steps
+// ahead), the writer until the reader is less than a ring behind.  The distance between two such bands is 80-95 steps
+// instead of the 128 + ~25 (latency) of the hand-off through memory.
+constexpr int kRing = 1024;                               // entries per ring (power of two); + 64 dummy entries for the lanes that store nothing
+struct LdsLink {
+    int2* ring_top;  int* done_up;                        // ring the band reads its top row from / steps the band above has finished (null: memory)
+    int2* ring_bot;  int* done_down;                      // ring its bottom row goes to / steps the band below has finished (null: memory)
+    int*  done_mine;
+};
+
+__device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* status, int lane)
+{
+    int spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if (lane == 0) atomicOr(status, 4u); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler ordering only: the LDS performs a wave's operations in issue order
+}
+
+template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT>
+__device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
+                                                   const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
+                                                   const LdsLink& L, const int S_total, unsigned* status)
+{
+    constexpr int SPB = TraceCfg<R>::SPB;
+    static_assert(16 % SPB == 0, "hand-off every 16 steps");
+#pragma unroll 1
+    for (int g = 0; g < 64 / SPB; ++g) {
+        const int ts = t0 + g * SPB;
+        if ((ts & 15) == 0) {
+            if (LTOP) {
+                // the band above has finished step ts+79: columns ts .. ts+15 are in the ring; they go to lanes 0..15, from where
+                // the per-step rotation of (th, te) brings one to lane 0 in each of the next 16 steps
+                lds_wait_ge(L.done_up, min(ts + 80, S_total), status, lane);
+                const int2 v = L.ring_top[(ts + (lane & 15)) & (kRing - 1)];
+                s.th = lane < 16 ? v.x : s.th; s.te = lane < 16 ? v.y : s.te;
+            }
+            if (LBOT) lds_wait_ge(L.done_down, ts + 32 - kRing, status, lane);   // the band below has read what is about to be overwritten
+        }
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < SPB; ++q) {
+            int tb[(R + 3) / 4];
+#pragma unroll
+            for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
+            trace_step<R, PRED, true, FULL>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
+            if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
+            else if constexpr (R == 4) { acc[q] = tb[0]; }
+            else { acc[(q * R) / 4] = (tb[0] << (8 * ((q * R) % 4))) + acc[(q * R) / 4]; }
+        }
+        tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
+                                        (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
+        if (((ts + SPB) & 15) == 0) {
+            const int te = ts + SPB;                         // steps finished; lanes 48..63 of (sh, se) hold columns te-80 .. te-65
+            if (LBOT) {
+                const int col = te - 80 + (lane - 48);
+                const int slot = (lane >= 48 && col >= 0) ? (col & (kRing - 1)) : kRing + lane;      // the others: dummy entries
+                L.ring_bot[slot] = make_int2(s.sh, s.se);
+            }
+            // (the LDS performs one wave's operations in issue order: the entries are in before the word says so)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_store(L.done_mine, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// One pair, one launch, four consecutive bands per workgroup: band 4b+j runs in wave j.  Inside the workgroup the bands are
+// linked through LDS rings (above); the first band of a workgroup takes its top row from memory and the last one leaves its
+// bottom row there, exactly as psa_trace_tile_kernel<.., PERSIST> does (sc1 stores, progress word, sc1 polls and loads).
+// Workgroups are assigned statically, so ALL of them must be resident: the host launches this kernel only when there are no
+// more workgroups than compute units; it then cannot deadlock (a band waits only for the band above).
+template <int R>
+__global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
+{
+    constexpr int NS = TraceCfg<R>::NS;
+    constexpr int SPB = TraceCfg<R>::SPB;
+    __shared__ int2 ring[3][kRing + 64];
+    __shared__ int done[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < 4) done[threadIdx.x] = 0;
+    __syncthreads();
+    const TraceJob& J = A.jobs[0];
+    const int w = blockIdx.x * 4 + wave, g = J.band0 + w;
+    if (w >= J.W) return;
+    const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O, S_total = J.S_total;
+    const uint8_t* __restrict__ seq_a = J.a;
+    const uint8_t* __restrict__ seq_b = J.b;
+    const int i0 = w * 64 * R + lane * R;
+    const int nvalid = m - i0;
+    int* st = J.state + (size_t)w * NS * 64 + lane;
+    TLane<R> s;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < m) ? (int)seq_b[i0 + k] : 0x100;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int hk = hcol0t(i0 + 1 + k, E, O);
+        s.hl[k] = hk;
+        s.fb[k] = hk + O;
+    }
+    s.hd = hcol0t(i0, E, O);
+    s.hbot = 0; s.ebot = 0; s.cch = 0; s.mx = kNegInfT;
+    s.sh = 0; s.se = 0; s.th = 0; s.te = 0;
+
+    const bool top_lds = wave > 0, bot_lds = wave < 3 && w + 1 < J.W;
+    LdsLink L;
+    L.ring_top = top_lds ? ring[wave - 1] : nullptr;  L.done_up = top_lds ? &done[wave - 1] : nullptr;
+    L.ring_bot = bot_lds ? ring[wave] : nullptr;      L.done_down = bot_lds ? &done[wave + 1] : nullptr;
+    L.done_mine = &done[wave];
+    const int2* __restrict__ top = J.rows + (size_t)w * J.row_stride;
+    int2* __restrict__ bot = J.rows + (size_t)(w + 1) * J.row_stride;
+    uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
+
+    for (int t0 = 0; t0 < S_total; t0 += 64) {
+        const int c = t0 + lane;
+        int na = 0;
+        if (!top_lds) {
+            if (w > 0) wait_progress(&A.progress[g - 1], min(t0 + 128, S_total), A.status, lane);
+            int2 nt = make_int2(0, 0);
+            if (c < n) nt = (w > 0) ? load_sc1_int2(&top[c]) : top[c];
+            s.th = nt.x; s.te = nt.y;
+        }
+        if (c < n) na = seq_a[c];
+        s.ach = na;
+        uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
+        const bool steady = t0 >= 64 && t0 + 63 < n;
+        const bool full = (w + 1) * 64 * R <= m;
+#define TSTA_LINKED(PRED_, FULL_)                                                                                                        \
+        do {                                                                                                                             \
+            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
+            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else                     trace_block_linked<R, PRED_, FULL_, false, false>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status); \
+        } while (0)
+        if (steady && full) TSTA_LINKED(false, true);
+        else if (steady)    TSTA_LINKED(false, false);
+        else                TSTA_LINKED(true, false);
+#undef TSTA_LINKED
+        if (!bot_lds) {
+            const int cs = t0 - 64 + lane;
+            if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
+            publish_progress(&A.progress[g], t0 + 64, lane);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = s.hl[k]; st[(2 * k + 1) * 64] = s.fb[k]; }
+    st[(2 * R) * 64] = s.hd; st[(2 * R + 1) * 64] = s.hbot; st[(2 * R + 2) * 64] = s.ebot;
+    st[(2 * R + 3) * 64] = s.cch; st[(2 * R + 4) * 64] = s.mx;
+}
+
 // PERSIST = false: one tile of the launch-per-diagonal pipeline (see file header).
 // PERSIST = true: ONE launch for the whole fill.  A wave draws a ticket = its band (bands of a job are consecutive), sweeps
 // all its steps, then draws the next ticket (the grid holds one wave per SIMD; there may be more bands than that).  Before
@@ -604,7 +759,12 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if (w_lo >= w_hi) return;
         g_lo = std::min(g_lo, band0 + w_lo); g_hi = std::max(g_hi, band0 + w_hi);
     };
-    if (persistent) {                                           // the singles' whole fill in one launch (flag hand-off)
+    if (persistent && TRACE && R == 2 && e->opt_trace_lds != 0 && (single_bands + 3) / 4 <= e->n_cu) {
+        // one pair, few enough bands that every workgroup of four is resident: bands linked through LDS inside a workgroup
+        A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
+        hipLaunchKernelGGL((psa_trace_quad_kernel<2>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
+        ++launches;
+    } else if (persistent) {                                    // the singles' whole fill in one launch (flag hand-off)
         A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
         hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, s, A);
         ++launches;
