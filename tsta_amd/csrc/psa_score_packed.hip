@@ -41,12 +41,23 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
     const int n = max(nA, nB), nmin = min(nA, nB);
     const int i0 = band_row0 + lane * R;
     const int nvA = mA - i0, nvB = mB - i0;
+    // The band hand-off row is kept as the kernel holds it: per column one dword H' and one dword Ebar', both pairs' biased
+    // 16-bit halves side by side (rowP), plus per 64-column block the two int32 bases those halves are relative to (rowS):
+    // 8 B per column and couple instead of the two int2 {H, Ebar} of 16 B (the row is this kernel's only HBM traffic).
+    // An entry read back differs from the reader's frame only by (writer's base - reader's base) per half.
+    uint2* __restrict__ rowP = reinterpret_cast<uint2*>(rowA);
+    int2* __restrict__ rowS = rowB;
     // anchor of the H' frame: the band's top row at the first column (H' = H - (column index + 1) * M)
-    int2 ntA = make_int2(0, 0), ntB = make_int2(0, 0);
+    uint2 pt = make_uint2(0u, 0u);
     int naA = 0, naB = 0;
-    { const int l0 = opaque(lane); if (l0 < nA) { ntA = rowA[l0]; naA = aA[l0]; } if (l0 < nB) { ntB = rowB[l0]; naB = aB[l0]; } }
-    acc.baseA = __builtin_amdgcn_readfirstlane(ntA.x) - M;
-    acc.baseB = __builtin_amdgcn_readfirstlane(ntB.x) - M;
+    { const int l0 = opaque(lane); if (l0 < n) pt = rowP[l0]; if (l0 < nA) naA = aA[l0]; if (l0 < nB) naB = aB[l0]; }
+    int2 bw = rowS[0];                              // bases of the block the entries in `pt` belong to
+    bw.x = __builtin_amdgcn_readfirstlane(bw.x); bw.y = __builtin_amdgcn_readfirstlane(bw.y);
+    {
+        const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)pt.x);
+        acc.baseA = (int)(p0 & 0xffffu) - kBias + bw.x;     // = H'(band's top row, column 0)
+        acc.baseB = (int)(p0 >> 16) - kBias + bw.y;
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int hk = hcol0p(i0 + 1 + k, E, O);   // column 0: H' = H
@@ -82,8 +93,9 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             // re-anchor both pairs to the band's top row at column t0
             fold_max<R>(s, acc);
             // (a pair whose columns are exhausted keeps its last anchor: its lanes hold garbage from here on)
-            const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
-            const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
+            const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)pt.x);
+            const int nbA = (t0 < nA) ? (int)(p0 & 0xffffu) - kBias + bw.x : acc.baseA;
+            const int nbB = (t0 < nB) ? (int)(p0 >> 16) - kBias + bw.y : acc.baseB;
             // (in the H* frame the reference column moves along with the block: +64|E| on everything)
             const int star = in_star ? -64 * F.col : 0;
             const unsigned pd = pack2(nbA - acc.baseA - star, nbB - acc.baseB - star);
@@ -100,16 +112,18 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         acc.ancB = acc.baseB + (t0 - 62) * M;
         s.joff = pack2((63 - ln) * M, (63 - ln) * M);
         {
-            const int sh_m = (t0 + ln + 1) * M;    // column shift of this lane's top-row entry
-            s.th = pack2(ntA.x - sh_m - acc.baseA + kBias, ntB.x - sh_m - acc.baseB + kBias);
-            s.te = pack2(ntA.y - sh_m - acc.baseA + kBias, ntB.y - sh_m - acc.baseB + kBias);
+            const unsigned dlt = pack2(bw.x - acc.baseA, bw.y - acc.baseB);     // the writer's frame -> this block's frame, per half
+            s.th = pkadd(pt.x, dlt);
+            s.te = pkadd(pt.y, dlt);
         }
         unsigned tabA = 0u, tabB = 0u;                 // this block's column tables (PERM) / characters
         if (PERM) { tabA = acgt_table(naA, k4); tabB = acgt_table(naB, k4); }
         else      tabA = pack2(naA << 8, naB << 8);
         const int cn = t0 + 64 + ln;
-        if (cn < nA) { ntA = rowA[cn]; naA = aA[cn]; }
-        if (cn < nB) { ntB = rowB[cn]; naB = aB[cn]; }
+        if (cn < n) pt = rowP[cn];
+        if (cn < nA) naA = aA[cn];
+        if (cn < nB) naB = aB[cn];
+        if (t0 + 64 < n) { bw = rowS[(t0 + 64) >> 6]; bw.x = __builtin_amdgcn_readfirstlane(bw.x); bw.y = __builtin_amdgcn_readfirstlane(bw.y); }
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
         bool elide = false;
         if (steady && elide_ok) {
@@ -138,11 +152,8 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
         const int cs = t0 - 64 + opaque(lane);
-        if (store_bottom && cs >= 0 && cs < n) {
-            const int sh_m = (cs + 1) * M;
-            rowA[cs] = make_int2((int)(s.sh & 0xffffu) - kBias + acc.baseA + sh_m, (int)(s.se & 0xffffu) - kBias + acc.baseA + sh_m);
-            rowB[cs] = make_int2((int)(s.sh >> 16) - kBias + acc.baseB + sh_m, (int)(s.se >> 16) - kBias + acc.baseB + sh_m);
-        }
+        if (store_bottom && cs >= 0 && cs < n) rowP[cs] = make_uint2(s.sh, s.se);      // this block's captures, in this block's frame
+        if (store_bottom && t0 >= 64 && ln == 0) rowS[(t0 - 64) >> 6] = make_int2(acc.baseA, acc.baseB);
     }
     fold_max<R>(s, acc);
 }
@@ -155,10 +166,14 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
                                               int& outA, int& outB)
 {
     const int n = max(nA, nB), mmax = max(mA, mB), mmin = min(mA, mB);
-    for (int c = opaque(lane); c < n; c += 64) {          // blockmatrix_init, psa.c:221-226
-        const int h = O + (c + 1) * E;
-        rowA[c] = make_int2(h, h + O);
-        rowB[c] = make_int2(h, h + O);
+    {   // blockmatrix_init, psa.c:221-226: H(0,c+1) = O + (c+1)E, Ebar = H + O, in the packed row format of pband: H' = H - (c+1)M
+        // relative to the block's first column
+        uint2* rowP = reinterpret_cast<uint2*>(rowA);
+        for (int c = opaque(lane); c < n; c += 64) {
+            const int rel = (c & 63) * (E - M);                    // H'(c) - H'(first column of the block)
+            rowP[c] = make_uint2(pack2(rel + kBias, rel + kBias), pack2(rel + O + kBias, rel + O + kBias));
+            if ((c & 63) == 0) { const int b0 = O + (c + 1) * (E - M); rowB[c >> 6] = make_int2(b0, b0); }
+        }
     }
     wave_mem_sync();
     PairAcc acc; acc.baseA = 0; acc.baseB = 0; acc.ancA = 0; acc.ancB = 0; acc.mxA = kNegInfP; acc.mxB = kNegInfP;
