@@ -463,12 +463,10 @@ def main():
                          "kernel": "psa_score_packed_kernel", "kernel_ms": kern_ms,
                          "note": "integer max-plus recurrence: VALU-issue-bound, HBM fraction is ~0 by construction "
                                  "(SURVEY 8d); see valu_roofline.  traffic (PMC, profiles/traffic_psa_score.json) is not "
-                                 "re-reading of inputs: it is the boundary row {H,Ebar} every 2048-row band hands to the "
-                                 "next (written once, read once: 8192 pairs x 24 hand-offs x 50000 columns x 8 B x 2), "
-                                 "77 GB/s = 1 % of HBM bandwidth"},
-            # data-sheet VALU peak (one wave64 instruction per 2 cycles per SIMD, reached only by pure add/sub/logic streams)
-            # and, next to it, the rate every stream containing max/min/perm/packed ops sustains on gfx950: one wave64
-            # instruction per 4 cycles per SIMD (16 lanes/cycle; tools/cell_microbench.hip)
+                                 "re-reading of inputs: it is the boundary row every 2048-row band hands to the next (per column "
+                                 "and couple 8 B: the packed 16-bit H' / Ebar' halves of both pairs; written once, read once: "
+                                 "4096 couples x 24 hand-offs x 50000 columns x 8 B x 2) plus the column sequence re-read per "
+                                 "band, ~1 % of HBM bandwidth"},
             "valu_roofline": valu,
         }
         out["ranks_seen"] = len(set(uuids))

@@ -46,10 +46,12 @@ if fe and wr:
     t = {"kernel": "psa_score_packed_kernel<32,2>", "pairs_per_gpu": 8192, "len": 50000,
          "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
          "fetch_correction": "x2: gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM); the expected "
-                             "boundary-row reads (8192 pairs x 24 band hand-offs x 50000 columns x 8 B = 78.6 GB) + sequence re-reads agree with 2x raw",
+                             "boundary-row reads (4096 couples x 24 band hand-offs x 50000 columns x 8 B = 39.3 GB) + sequence re-reads "
+                             "(24 x 0.41 GB) agree with 2x raw",
          "hbm_bytes_per_launch": 2 * fb + wb, "pmc_rows": fe + wr,
-         "what_it_is": "band hand-off rows ({H,Ebar} int32 per column per 2048-row band), i.e. workspace traffic, <1% of HBM bandwidth; "
-                       "algorithmic bytes are 0.82 GB per launch",
+         "what_it_is": "band hand-off rows (per column and couple one dword H' + one dword Ebar', both pairs' 16-bit halves side by side, "
+                       "per 2048-row band; round 1 stored two int2 = 16 B), i.e. workspace traffic, <1% of HBM bandwidth; algorithmic "
+                       "bytes are 0.82 GB per launch",
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                     "--no-cpu-baseline --no-generic (separate passes)"}
     json.dump(t, open(os.path.join(out, "traffic_psa_score.json"), "w"), indent=1)
