@@ -16,8 +16,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     V = int(rng.integers(1, 1800)); mp = int(rng.integers(1, 9)); n = int(rng.integers(1, 1500))
     pred_off, pred, base, is_sink, seq = random_dag(int(rng.integers(1 << 30)), V, mp, n)
     prm = tsta_amd.Params(M, X, E, O)
-    for cols, skewed in ((2, 0), (4, 0), (2, 1)):
-        eng.set_option("poa_cols", cols); eng.set_option("poa_skewed", skewed)
+    if trial % 3 == 0:                                     # literal N in the sequence (K4's segment-by-segment path)
+        seq = seq.copy(); seq[rng.integers(0, len(seq), size=max(1, len(seq) // 40))] = ord("N")
+    for cols, dataflow in ((2, 1), (2, 0), (4, 0)):        # K4d (solver + emitters), K4 with 2 / 4 columns per lane
+        eng.set_option("poa_cols", cols); eng.set_option("poa_dataflow", dataflow)
         got = eng.poa_fill(pred_off, pred, base, is_sink, seq, prm)
         want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq, M=M, X=X, E=E, O=O)
         ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
@@ -26,6 +28,6 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         ok = ok and end_col == wend and [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps] == wsteps
         if not ok:
             bad += 1
-            print("MISMATCH", trial, (M, X, E, O), (V, mp, n), (cols, skewed), flush=True)
-    eng.set_option("poa_cols", 0); eng.set_option("poa_skewed", 0)
+            print("MISMATCH", trial, (M, X, E, O), (V, mp, n), (cols, dataflow), flush=True)
+    eng.set_option("poa_cols", 0); eng.set_option("poa_dataflow", 1)
 print("mismatches:", bad, "%.0f s" % (time.time() - t0))

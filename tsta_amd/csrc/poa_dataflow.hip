@@ -51,7 +51,7 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
     int spins = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 18)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~30 ms
+        if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~1 s: far beyond any ramp-up of the chunks
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;

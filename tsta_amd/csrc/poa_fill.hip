@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
             if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + 64) break;   // restage
+            int probed_code = -1;                              // source code of (num1, num2) if the probe below has read it
             if (forced < 0) {
                 // ---- run of match / mismatch cells along the backbone, taken at once: lane l probes cell
                 // (num1 - l, num2 - l); the run continues while the cell is a diagonal move (:786-860, :861-956) whose
@@ -534,9 +535,11 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                     ns += run; num1 -= run; num2 -= run;
                     continue;
                 }
+                if (__builtin_amdgcn_readfirstlane(have ? 1 : 0)) probed_code = __builtin_amdgcn_readfirstlane(code_l);   // lane 0 probed (num1, num2) itself
             }
             int code;
-            if (forced >= 0) { code = forced; forced = -1; } else code = __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
+            if (forced >= 0) { code = forced; forced = -1; }
+            else code = probed_code >= 0 ? probed_code : __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
             const int kind = code / 42, pidx = code % 42;
             const int wi = num1 - rw0;                          // in the window (checked above)
             const int np = wnp[wi];
