@@ -57,7 +57,8 @@ def random_dag(seed, V, max_pred, n):
 
 
 @pytest.mark.parametrize("seed,V,max_pred,n", [(1, 50, 3, 40), (2, 300, 8, 1), (3, 64, 41, 700), (4, 1000, 5, 9),
-                                               (5, 700, 12, 8193), (6, 1, 0, 100), (7, 400, 2, 1025)])
+                                               (5, 700, 12, 8193), (6, 1, 0, 100), (7, 400, 2, 1025),
+                                               (8, 2500, 3, 16384), (9, 300, 2, 16385)])      # 128 chunks: the widest K4d runs; one more column: K4
 def test_random_dags_vs_oracle(eng, seed, V, max_pred, n):
     pred_off, pred, base, is_sink, seq = random_dag(seed, V, max_pred, n)
     for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0)):

@@ -138,13 +138,13 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
 }
 
 // ---- the four bands of one workgroup handed to each other through LDS (psa_trace_quad_kernel below) -----------------------
-// A band's bottom row reaches the band below as one {H, Ebar} entry per column in an LDS ring, 16 columns at a time and
-// through the registers the memory hand-off uses: after every 16 steps lanes 48..63 of the capture registers (sh, se) hold
-// the 16 columns lane 63 finished last (t-79 .. t-64 after step t): one LDS store; the band below refills lanes 0..15 of its
-// top-row registers (th, te) with the 16 columns its next 16 steps consume: one LDS load.  Nothing is added to a step.
-// Flow control at the same moments: the reader waits until the writer's `done` word covers its 16 columns (writer 80 steps
-// ahead), the writer until the reader is less than a ring behind.  The distance between two such bands is 80-95 steps
-// instead of the 128 + ~25 (latency) of the hand-off through memory.
+// A band's bottom row reaches the band below as one {H, Ebar} entry per column in an LDS ring, G = 16 columns at a time and
+// through the registers the memory hand-off uses: after every G steps the top G lanes of the capture registers (sh, se)
+// hold the G columns lane 63 finished last (t-63-G .. t-64 after step t): one LDS store; the band below refills lanes
+// 0..G-1 of its top-row registers (th, te) with the G columns its next G steps consume: one LDS load.  Nothing is added to
+// a step.  Flow control at the same moments: the reader waits until the writer's `done` word covers its G columns (writer
+// 64+G steps ahead), the writer until the reader is less than a ring behind.  The distance between two such bands is
+// 80-95 steps instead of the 128 + ~25 (latency) of the hand-off through memory (measured on 100 kbp: G = 8: 28.4 ms, 16: 27.6, 32: 27.8).
 constexpr int kRing = 1024;                               // entries per ring (power of two); + 64 dummy entries for the lanes that store nothing
 struct LdsLink {
     int2* ring_top;  int* done_up;                        // ring the band reads its top row from / steps the band above has finished (null: memory)
@@ -162,23 +162,26 @@ __device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* statu
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler ordering only: the LDS performs a wave's operations in issue order
 }
 
+constexpr int kLinkG = 16;                                // columns per LDS hand-off (16 / R steps make one trace group: G is a multiple of it)
+
 template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT>
 __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                                    const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
                                                    const LdsLink& L, const int S_total, unsigned* status)
 {
     constexpr int SPB = TraceCfg<R>::SPB;
-    static_assert(16 % SPB == 0, "hand-off every 16 steps");
+    constexpr int G = kLinkG;
+    static_assert(G % SPB == 0 && 64 % G == 0, "hand-off every G steps");
 #pragma unroll 1
     for (int g = 0; g < 64 / SPB; ++g) {
         const int ts = t0 + g * SPB;
-        if ((ts & 15) == 0) {
+        if ((ts & (G - 1)) == 0) {
             if (LTOP) {
-                // the band above has finished step ts+79: columns ts .. ts+15 are in the ring; they go to lanes 0..15, from where
-                // the per-step rotation of (th, te) brings one to lane 0 in each of the next 16 steps
-                lds_wait_ge(L.done_up, min(ts + 80, S_total), status, lane);
-                const int2 v = L.ring_top[(ts + (lane & 15)) & (kRing - 1)];
-                s.th = lane < 16 ? v.x : s.th; s.te = lane < 16 ? v.y : s.te;
+                // the band above has finished step ts+G-1+64: columns ts .. ts+G-1 are in the ring; they go to lanes 0..G-1, from
+                // where the per-step rotation of (th, te) brings one to lane 0 in each of the next G steps
+                lds_wait_ge(L.done_up, min(ts + G + 64, S_total), status, lane);
+                const int2 v = L.ring_top[(ts + (lane & (G - 1))) & (kRing - 1)];
+                s.th = lane < G ? v.x : s.th; s.te = lane < G ? v.y : s.te;
             }
             if (LBOT) lds_wait_ge(L.done_down, ts + 32 - kRing, status, lane);   // the band below has read what is about to be overwritten
         }
@@ -195,11 +198,11 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
         }
         tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
                                         (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
-        if (((ts + SPB) & 15) == 0) {
-            const int te = ts + SPB;                         // steps finished; lanes 48..63 of (sh, se) hold columns te-80 .. te-65
+        if (((ts + SPB) & (G - 1)) == 0) {
+            const int te = ts + SPB;                         // steps finished; lanes 64-G..63 of (sh, se) hold columns te-64-G .. te-65
             if (LBOT) {
-                const int col = te - 80 + (lane - 48);
-                const int slot = (lane >= 48 && col >= 0) ? (col & (kRing - 1)) : kRing + lane;      // the others: dummy entries
+                const int col = te - 64 - G + (lane - (64 - G));
+                const int slot = (lane >= 64 - G && col >= 0) ? (col & (kRing - 1)) : kRing + lane;      // the others: dummy entries
                 L.ring_bot[slot] = make_int2(s.sh, s.se);
             }
             // (the LDS performs one wave's operations in issue order: the entries are in before the word says so)
