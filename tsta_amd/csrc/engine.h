@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
 
 namespace tsta {
 
@@ -38,6 +39,9 @@ struct Engine {
     DevBuf scratch;
     DevBuf scratch2;
     DevBuf unpacked;     // ASCII copy of 2-bit packed input (tsta_psa_score_batch*_2bit)
+    DevBuf unpacked2;    // K1b single-launch form: ticket / progress words and the tile table
+    std::vector<int> host_tab;   // host copy of that table: must outlive the asynchronous upload ...
+    hipEvent_t ev_tab = nullptr; // ... which this event marks the end of (waited for before the table is rewritten)
     DevBuf pair_flags;   // per-pair alphabet flags of the packed score kernel
 
     void set_error(const char* fmt, ...);

@@ -172,13 +172,14 @@ void tsta_engine_destroy(tsta_engine* eng)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
-                            &e->scratch2, &e->pair_flags, &e->unpacked}) {
+                            &e->scratch2, &e->pair_flags, &e->unpacked, &e->unpacked2}) {
         if (b->p) (void)hipFree(b->p);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (int g = 0; g < 3; ++g) { if (e->side[g]) (void)hipStreamDestroy(e->side[g]); if (e->ev_join[g]) (void)hipEventDestroy(e->ev_join[g]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_tab) (void)hipEventDestroy(e->ev_tab);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -194,7 +195,7 @@ int tsta_engine_release_workspaces(tsta_engine* eng)
     if ((rc = e->check(hipStreamSynchronize(e->stream), "hipStreamSynchronize")) != TSTA_OK) return rc;
     // everything but the small counter block (ticket words, self-test / result scalars)
     for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
-                            &e->pair_flags, &e->unpacked}) {
+                            &e->pair_flags, &e->unpacked, &e->unpacked2}) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr; b->bytes = 0;
     }

@@ -77,8 +77,13 @@ struct PsaBandsArgs {
     int64_t  rows_per_pair;         // (W_max+1) * row_stride
     int      W_max, T, d;           // bands per pair at max_len, tile length (steps), launch index
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves
+    // single-launch (dataflow) form: the same tiles as tickets, d-major; "launch" d = tiles tile_first[d] .. = bands
+    // tile_wlo[d] .. tile_wlo[d] + tile_nw[d] - 1 of every couple; progress[couple * W_max + band] = steps published
+    unsigned* ticket; int* progress; unsigned* status;
+    const int* tile_first; const int* tile_wlo; const int* tile_nw; int n_d, n_tiles;
 };
 void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream);
+void launch_psa_score_bands_persistent(int R, const PsaBandsArgs& args, int n_cu, hipStream_t stream);
 void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t stream);
 
 void launch_psa_score_batch(int R, const PsaBatchArgs& args, int blocks, hipStream_t stream);

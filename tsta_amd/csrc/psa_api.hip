@@ -250,6 +250,45 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         const int64_t D = (S_total + (int64_t)(ba.W_max - 1) * (ba.T + 64) + ba.T - 1) / ba.T;
         const int64_t bblocks = (couples * ba.W_max + 3) / 4;
         if (bblocks > 0x7fffffffLL) return TSTA_ERR_UNSUPPORTED;
+        ba.ticket = nullptr; ba.progress = nullptr; ba.status = nullptr; ba.tile_first = ba.tile_wlo = ba.tile_nw = nullptr; ba.n_d = 0; ba.n_tiles = 0;
+        bool dataflow = e->opt_trace_persistent != 0 && couples * ba.W_max <= (1 << 22) && D <= (1 << 20);
+        std::vector<int>& tab = e->host_tab;
+        if (dataflow) {
+            if (e->ev_tab) (void)hipEventSynchronize(e->ev_tab);          // the previous call's upload of this vector has finished
+            else if (hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming) != hipSuccess) { e->ev_tab = nullptr; dataflow = false; }
+        }
+        if (dataflow) {
+            // ONE launch: the tiles of the D launches as tickets, d-major (psa_trace_packed.hip, psa_score_bands_kernel<.., true>)
+            tab.assign((size_t)(3 * D + 1), 0);
+            int64_t total = 0;
+            for (int64_t d = 0; d < D; ++d) {
+                // bands with work in launch d: S_w(d) > 0 and S_w(d-1) < S_total  (as psa_trace.hip: active())
+                int64_t w_hi = ((d + 1) * ba.T + (ba.T + 64) - 1) / (ba.T + 64);
+                const int64_t w_lo = (d * ba.T - S_total < 0) ? 0 : (d * ba.T - S_total) / (ba.T + 64);
+                w_hi = std::min<int64_t>(ba.W_max, w_hi);
+                const int64_t nw = std::max<int64_t>(0, w_hi - w_lo);
+                tab[(size_t)d] = (int)total; tab[(size_t)(D + 1 + d)] = (int)w_lo; tab[(size_t)(2 * D + 1 + d)] = (int)std::max<int64_t>(nw, 1);
+                total += couples * nw;
+                if (total > 0x7fffffff) { dataflow = false; break; }
+            }
+            tab[(size_t)D] = (int)total;
+            const size_t sync_ints = 64 + (size_t)couples * ba.W_max, tab_ints = tab.size();
+            if (dataflow && e->reserve(e->unpacked2, (sync_ints + tab_ints) * sizeof(int) + 256, "hipMalloc(band tickets)") == TSTA_OK) {
+                int* d_sync = reinterpret_cast<int*>(e->unpacked2.p);
+                if ((rc = e->check(hipMemsetAsync(d_sync, 0, sync_ints * sizeof(int), s), "hipMemsetAsync(band tickets)")) ||
+                    (rc = e->check(hipMemcpyAsync(d_sync + sync_ints, tab.data(), tab_ints * sizeof(int), hipMemcpyHostToDevice, s), "H2D tile table")))
+                    return rc;
+                (void)hipEventRecord(e->ev_tab, s);             // `tab` is the engine's: it is not touched again before this event has passed
+                ba.ticket = reinterpret_cast<unsigned*>(d_sync); ba.status = reinterpret_cast<unsigned*>(d_sync + 1); ba.progress = d_sync + 64;
+                ba.tile_first = d_sync + sync_ints; ba.tile_wlo = ba.tile_first + D + 1; ba.tile_nw = ba.tile_wlo + D;
+                ba.n_d = (int)D; ba.n_tiles = (int)total;
+            } else dataflow = false;
+        }
+        if (dataflow) {
+            ba.d = 0;
+            tsta::launch_psa_score_bands_persistent(Rb, ba, e->n_cu, s);
+            ++launches;
+        } else
         for (int64_t d = 0; d < D; ++d) {
             ba.d = (int)d;
             tsta::launch_psa_score_bands(Rb, ba, (int)bblocks, s);

@@ -443,17 +443,33 @@ __global__ void psa_trace_packed_finish_kernel(const TraceJob* jobs, const Trace
 // Couples and orientation exactly as in K1p (adjacent pairs of the geometry order, psa_couple_is_packed; K1 takes the
 // rest); workspaces are laid out uniformly for max_len so that a wave finds its couple and band by division:
 //   band g -> couple g / W_max, band g % W_max;  rows: [pair][W_max+1][row_stride] int2;  state: [couple][W_max][2R+8][64]
-template <int R>
+// PERSIST: the same tiles as ONE launch in dataflow form (see psa_trace_packed_tile_kernel<.., true>): tickets enumerate the
+// tiles d-major, a wave waits for the band's previous tile and the upper band's tile 64 steps further, runs the tile with sc1
+// loads / stores of rows and lane state, publishes.
+template <int R, bool PERSIST>
 __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
 {
     constexpr int NS = packed_state_ints(R);
     const PsaBatchArgs& A = P.b;
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t c = g / P.W_max;
-    const int w = (int)(g % P.W_max);
-    if (c >= A.packed_couples) return;
-    if (!psa_couple_is_packed(A.len1, A.len2, A.order, c)) return;          // K1 (int32) takes these two pairs
+    for (;;) {
+    int64_t c; int w, d = P.d;
+    if (PERSIST) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(P.ticket, 1u);
+        const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
+        if (t >= P.n_tiles) return;
+        int lo = 0, hi = P.n_d - 1;             // d = last one whose first tile is <= t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P.tile_first[mid] <= t) lo = mid; else hi = mid - 1; }
+        d = lo;
+        const int idx = t - P.tile_first[d], nw = P.tile_nw[d];
+        c = idx / nw; w = P.tile_wlo[d] + idx % nw;
+    } else {
+        const int64_t g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        c = g / P.W_max; w = (int)(g % P.W_max);
+    }
+    if (c >= A.packed_couples) { if (PERSIST) continue; return; }
+    if (!psa_couple_is_packed(A.len1, A.len2, A.order, c)) { if (PERSIST) continue; return; }   // K1 (int32) takes these two pairs
     const int64_t pa = psa_pair_at(A.order, 2 * c), pb = psa_pair_at(A.order, 2 * c + 1);
     const int l1a = A.len1[pa], l2a = A.len2[pa], l1b = A.len1[pb], l2b = A.len2[pb];
     const uint8_t* s1a = A.seqs + A.off1[pa]; const uint8_t* s2a = A.seqs + A.off2[pa];
@@ -464,13 +480,13 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     V.nA = swa ? l2a : l1a; V.mA = swa ? l1a : l2a; V.nB = swb ? l2b : l1b; V.mB = swb ? l1b : l2b;
     const int n = max(V.nA, V.nB), m = max(V.mA, V.mB);
     const int W = (m + 64 * R - 1) / (64 * R);
-    if (w >= W) return;
+    if (w >= W) { if (PERSIST) continue; return; }
     const int S_total = (n + 64 + 63) / 64 * 64;
     const int shift = w * (P.T + 64);
-    int s0 = P.d * P.T - shift, s1 = (P.d + 1) * P.T - shift;
+    int s0 = d * P.T - shift, s1 = (d + 1) * P.T - shift;
     s0 = max(0, min(s0, S_total));
     s1 = max(0, min(s1, S_total));
-    if (s0 >= s1) return;
+    if (s0 >= s1) { if (PERSIST) continue; return; }
     int2* rowsA = A.rows + (size_t)(2 * c) * P.rows_per_pair;
     int2* rowsB = rowsA + P.rows_per_pair;
     V.topA = w ? rowsA + (size_t)w * A.row_stride : nullptr; V.topB = w ? rowsB + (size_t)w * A.row_stride : nullptr;
@@ -479,11 +495,19 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     V.tbandA = nullptr; V.tbandB = nullptr;
     V.st = P.state + ((size_t)c * P.W_max + w) * NS * 64;
     V.w = w;
+    int* prog = PERSIST ? P.progress + (size_t)c * P.W_max + w : nullptr;
+    if (PERSIST) {
+        if (s0 > 0) wait_progress(prog, s0, P.status, lane);                                   // this band's previous tile
+        if (w > 0)  wait_progress(prog - 1, min(s1 + 64, S_total), P.status, lane);            // the band above, 64 steps further
+    }
     // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
     const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
-    if (perm && P.ffree) packed_tile<R, false, true, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
-    else if (perm)       packed_tile<R, false, true>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
-    else                 packed_tile<R, false, false>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    if (perm && P.ffree) packed_tile<R, false, true, true, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    else if (perm)       packed_tile<R, false, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    else                 packed_tile<R, false, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    if (!PERSIST) return;
+    publish_progress(prog, s1, lane);
+    }
 }
 
 // per couple (blockIdx.x): out[pair] = max over the bands' lanes, floored at -100 (psa.c:110,590)
@@ -516,8 +540,19 @@ __global__ void psa_score_bands_finish_kernel(PsaBandsArgs P)
 
 void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream)
 {
-    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16>), dim3(blocks), dim3(256), 0, stream, args);
-    else         hipLaunchKernelGGL((psa_score_bands_kernel<8>), dim3(blocks), dim3(256), 0, stream, args);
+    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16, false>), dim3(blocks), dim3(256), 0, stream, args);
+    else         hipLaunchKernelGGL((psa_score_bands_kernel<8, false>), dim3(blocks), dim3(256), 0, stream, args);
+}
+
+void launch_psa_score_bands_persistent(int R, const PsaBandsArgs& args, int n_cu, hipStream_t stream)
+{
+    int nb = 0;
+    hipError_t e = (R == 16) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<16, true>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<8, true>, 256, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(((int64_t)args.n_tiles + 3) / 4, (int64_t)n_cu * std::min(nb, 2)));
+    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    else         hipLaunchKernelGGL((psa_score_bands_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
 }
 
 void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t stream)
