@@ -762,15 +762,28 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if (w_lo >= w_hi) return;
         g_lo = std::min(g_lo, band0 + w_lo); g_hi = std::max(g_hi, band0 + w_hi);
     };
-    if (persistent && TRACE && R == 2 && e->opt_trace_lds != 0 && (single_bands + 3) / 4 <= e->n_cu) {
+    // The odd job out of a group of couples runs BESIDE their launch, on a side stream (both single-launch forms take work as
+    // tickets and wait only for work that is already running, so neither needs the other's waves to be resident); alone, it
+    // has the chip to itself and may use the statically assigned workgroups of four linked bands.
+    hipStream_t ss = s;
+    bool single_on_side = false;
+    if (persistent && persistent_couples) {
+        if (!e->side[0] && hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking) != hipSuccess) e->side[0] = nullptr;
+        if (!e->ev_join[0] && hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming) != hipSuccess) e->ev_join[0] = nullptr;
+        if (!e->ev_fork && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) e->ev_fork = nullptr;
+        if (e->side[0] && e->ev_join[0] && e->ev_fork &&
+            hipEventRecord(e->ev_fork, s) == hipSuccess && hipStreamWaitEvent(e->side[0], e->ev_fork, 0) == hipSuccess) { ss = e->side[0]; single_on_side = true; }
+    }
+    if (persistent && !persistent_couples && TRACE && R == 2 && e->opt_trace_lds != 0 && (single_bands + 3) / 4 <= e->n_cu) {
         // one pair, few enough bands that every workgroup of four is resident: bands linked through LDS inside a workgroup
         A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
         hipLaunchKernelGGL((psa_trace_quad_kernel<2>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
         ++launches;
     } else if (persistent) {                                    // the singles' whole fill in one launch (flag hand-off)
         A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
-        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, ss, A);
         ++launches;
+        if (single_on_side && ((rc = e->check(hipEventRecord(e->ev_join[0], ss), "hipEventRecord(join)")))) return rc;
     }
     std::vector<int> tile_tab;                                  // [first tile of d ...][D + 1], then [g_lo(d) ...][D]
     if (persistent_couples) {
@@ -819,6 +832,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             (rc = e->check(hipStreamWaitEvent(s, e->ev_join[q - 1], 0), "hipStreamWaitEvent(join)")))
             return rc;
     }
+    if (single_on_side && (rc = e->check(hipStreamWaitEvent(s, e->ev_join[0], 0), "hipStreamWaitEvent(join)"))) return rc;
     if (n_singles) hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_singles), dim3(256), 0, s, d_singles);
     if (n_couples) launch_psa_trace_packed_finish(d_jobs, d_couples, n_couples, s);     // (does not use band0)
     if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(n_jobs), dim3(64), 0, s, d_jobs);
