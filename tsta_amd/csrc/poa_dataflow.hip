@@ -34,14 +34,18 @@ namespace tsta {
 constexpr int kDfKC = 2;                 // columns per lane
 constexpr int kDfCW = 64 * kDfKC;        // columns per chunk
 constexpr int kDfRB = 32;                // nodes per block
+constexpr int kDfThreads = 320;           // solver, three emitters, fetcher
 constexpr int kDfRing = 2 * kDfRB;       // rows whose records stay in LDS: this block and the one before (7 x 64 x 64 ints = 112 KB)
 
-// What the solver leaves per lane and row, field-major in LDS (rec[field][row][lane]: every access is 64 consecutive
-// dwords, conflict-free).  A BACKBONE row (one predecessor = the row before it, not the first row of a block) gets only
+// What the solver leaves per lane and row in LDS (rec[row][field][lane]: every access is 64 consecutive dwords,
+// conflict-free; the fields of a row are reached from one address).  A BACKBONE row (one predecessor = the row before it, not the first row of a block) gets only
 // H, Eagg and F: everything else a trace code needs, the emitter recomputes from the record of the row above.  Any other
 // row also gets META: per column (16 bits each) jq | je(7 bits, bit 6 = "opened") << 6 | (bq==H) << 13 | (be==H) << 14 |
 // F-open flag << 15.
 enum { F_HS0, F_HS1, F_ES0, F_ES1, F_FL0, F_FL1, F_META, F_COUNT };
+// What the fetcher wave stages per row of a block: the DAG metadata (offset / number of predecessors, the first four of them
+// with their row slots, the node's base) and what the chunk on the left handed over (F carry, open flag, edge H).
+enum { FB_POFF, FB_NP, FB_PR0, FB_PR1, FB_PR2, FB_PR3, FB_PS0, FB_PS1, FB_PS2, FB_PS3, FB_BASE, FB_XIN, FB_FLAG, FB_EDGE, FB_COUNT };
 
 __device__ __forceinline__ int df_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
 
@@ -52,6 +56,8 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~1 s: far beyond any ramp-up of the chunks
+        // once any wave of the launch has given up, nobody waits any more
+        if ((spins & 4095) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
@@ -61,25 +67,29 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
 // inclusive scan over the 64 lanes (DPP, VALU only), fix-up pass with the true carry (poa_fill.hip has the derivation).
 // Out: H, F per column, per column whether F(c+1) opens from H(c).  (The carry leaving the chunk is max(F, H+O) of the last
 // column: the emitters take it from lane 63's record.)
-__device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, int lane, int E, int O, int aK, int w15, int w31,
-                                            int (&hs)[kDfKC], int (&fl)[kDfKC], int (&opn_next)[kDfKC])
+__device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, int cl, int cl1,
+                                            int E, int O, int (&hs)[kDfKC], int (&fl)[kDfKC], int (&opn_next)[kDfKC])
 {
-    int fbar = kNeg;
+    // local pass, no carry-in: F of the lane's first column is -inf, so H = a there (every a is a real score)
+    int fbar = a[0] + O;
 #pragma unroll
-    for (int k = 0; k < kDfKC; ++k) {
+    for (int k = 1; k < kDfKC; ++k) {
         const int f = fbar + E;
         const int h = max(a[k], f);
         fbar = max(f, h + O);
     }
-    int v = fbar;
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x111, 0xf, 0xf, false) + aK);
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x112, 0xf, 0xf, false) + 2 * aK);
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x114, 0xf, 0xf, false) + 4 * aK);
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x118, 0xf, 0xf, false) + 8 * aK);
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x142, 0xa, 0xf, false) + w15);
-    v = max(v, __builtin_amdgcn_update_dpp(kNeg, v, 0x143, 0xc, 0xf, false) + w31);
-    const int prev = df_shr1(kNeg, v);
-    fbar = max(prev, xin_row + lane * aK);
+    // Carry entering lane l = max(xin + l*aK, max_{j<l} fbar_j + (l-1-j)*aK).  In the frame u_j = fbar_j - (j+1)*aK the
+    // max-plus scan is a plain max scan: t = u shifted one lane up with xin entering lane 0, inclusive max scan of t
+    // (six v_max_i32_dpp: a lane without a source keeps its value), carry = scan + l*aK.
+    const int kMin = (int)0x80000000;
+    int t = df_shr1(xin_row, fbar - cl1);
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x111, 0xf, 0xf, false));
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x112, 0xf, 0xf, false));
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x114, 0xf, 0xf, false));
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x118, 0xf, 0xf, false));
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x142, 0xa, 0xf, false));
+    t = max(t, __builtin_amdgcn_update_dpp(kMin, t, 0x143, 0xc, 0xf, false));
+    fbar = t + cl;
 #pragma unroll
     for (int k = 0; k < kDfKC; ++k) {
         const int f = fbar + E;
@@ -91,93 +101,155 @@ __device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, 
     }
 }
 
-__global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
+__global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 {
     const PoaArgs& A = P.A;
-    __shared__ int rec[F_COUNT][kDfRing][64];            // 112 KB, row r in slot r % 64
+    __shared__ int rec[kDfRing][F_COUNT][64];            // 112 KB, row r in slot r % 64
     __shared__ int row_edge[kDfRing];                    // H(row, cbase): the column left of the chunk
-    __shared__ int row_h0[kDfRing];                      // chunk 0: H(row, 0)
     __shared__ int row_flag[kDfRing];                    // "F of the chunk's first column opens" of each row
     __shared__ int row_kind[kDfRing];                    // 1: backbone record (no META), 0: full record
     __shared__ int produced;                             // rows the solver has finished since the kernel began
     __shared__ int blk_done[4];                          // waves (of 4) that have finished block b, slot b & 3
     __shared__ int blk_pub;                              // blocks published (all four waves done, stores drained)
+    __shared__ int fbuf[2][FB_COUNT][kDfRB];             // what the fetcher read for block b (slot b & 1), one row per entry
+    __shared__ int fetched;                              // blocks the fetcher has put into fbuf
+    __shared__ int taken;                                // blocks the solver has copied out of fbuf
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
     const int aK = kDfKC * E;
     const int ncar = A.nchunks + 1;
-    const int w15 = ((lane & 15) + 1) * aK, w31 = (lane - 31) * aK;
+    const int cl = lane * aK, cl1 = (lane + 1) * aK;
 
-    if (threadIdx.x == 0) { produced = 0; blk_pub = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
+    if (threadIdx.x == 0) { produced = 0; blk_pub = 0; fetched = 0; taken = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
     __syncthreads();
-    const int q = blockIdx.x;                            // this workgroup's chunk
+    const int q = blockIdx.x;                            // this workgroup's chunk; workgroup nchunks is the column-0 solver below
+    if (q == A.nchunks) {
+        // ================================================================ column 0 (c-t-simd.c:174-188, 194-200)
+        // H(r, 0) = max over predecessors H(p, 0) + E (a source: O + E) depends on the graph only.  One wave walks the nodes
+        // ahead of chunk 0 and hands it, per row, what every other chunk gets from the chunk on its left: the F carry
+        // (F(r, 0) = -inf, so the carry is H + O and the first F opens), and H at the "edge".  Chunk 0 is then a chunk like
+        // any other.
+        if (wave != 0) return;
+        const int nblk = (A.V + kDfRB - 1) / kDfRB;
+        for (int rb = 0; rb < nblk; ++rb) {
+            const int r0 = rb * kDfRB, nrows = min(A.V, r0 + kDfRB) - r0;
+            int poff = 0, np = 0, pr[4] = {-1, -1, -1, -1};
+            int ext = kNeg;                              // max H(p, 0) over the predecessors before this block, one row per lane
+            if (lane < nrows) {
+                poff = A.pred_off[r0 + lane]; np = A.pred_off[r0 + lane + 1] - poff;
+                for (int j = 0; j < np; ++j) {
+                    const int p = A.pred[poff + j];
+                    if (j < 4) pr[j] = p;
+                    if (p < r0) ext = max(ext, load_sc1_int(&P.edge[(size_t)p * ncar]));
+                }
+            }
+            int h_l = 0;                                 // lane i: H(r0 + i, 0)
+            for (int i = 0; i < nrows; ++i) {
+                const int npi = __builtin_amdgcn_readlane(np, i);
+                int h = OE;
+                if (npi > 0) {
+                    h = __builtin_amdgcn_readlane(ext, i);
+                    const int p0 = __builtin_amdgcn_readlane(poff, i);
+                    for (int j = 0; j < npi; ++j) {
+                        int p;
+                        if (j == 0) p = __builtin_amdgcn_readlane(pr[0], i);
+                        else if (j == 1) p = __builtin_amdgcn_readlane(pr[1], i);
+                        else if (j == 2) p = __builtin_amdgcn_readlane(pr[2], i);
+                        else if (j == 3) p = __builtin_amdgcn_readlane(pr[3], i);
+                        else p = __builtin_amdgcn_readfirstlane(A.pred[p0 + j]);
+                        if (p >= r0) h = max(h, __builtin_amdgcn_readlane(h_l, p - r0));
+                    }
+                    h += E;
+                }
+                h_l = (lane == i) ? h : h_l;
+            }
+            if (lane < nrows) {
+                store_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar], h_l + O);
+                store_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar], 1);
+                store_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar], h_l);
+            }
+            publish_progress(P.prog, rb + 1, lane);
+        }
+        return;
+    }
     const int cbase = q * kDfCW, c0 = cbase + lane * kDfKC;
     int sch[kDfKC];
 #pragma unroll
     for (int k = 0; k < kDfKC; ++k) sch[k] = (c0 + k < n) ? (int)A.seq[c0 + k] : -1;
     int rows_base = 0;                                   // rows the solver has produced in earlier blocks
     // solver state that lives across blocks: the row just finished (the backbone predecessor of the next one)
-    int hs_prev[kDfKC] = {0, 0}, es_prev[kDfKC] = {0, 0}, prev_r = -2, h0_prev = 0, edge_prev = 0;
+    int hs_prev[kDfKC] = {0, 0}, es_prev[kDfKC] = {0, 0}, prev_r = -2, edge_prev = 0;
     const int nblocks = (A.V + kDfRB - 1) / kDfRB;
-    // Solver only: the DAG metadata of a block's rows (one row per lane: offset / number of predecessors, the first four of
-    // them with their row slots) is loaded one block AHEAD, and so is what the chunk on the left handed over (F carry,
-    // open flag, edge H) when it has already published that block — the usual case once the chunks have spread out.
-    // None of these loads then sits on the chain of rows.
-    struct Meta { int poff, np, pr[4], ps[4]; };
-    auto load_meta = [&](int row0, int count) -> Meta {
-        Meta m; m.poff = 0; m.np = 0;
+    if (wave == 4) {
+        // ================================================================ fetcher
+        // Everything the solver needs from global memory at the start of a block — the DAG metadata of its rows and what the
+        // chunk on the left handed over — is read by this wave up to two blocks ahead and left in LDS: no global-memory
+        // latency (and no wait for a neighbour's flag) sits on the chain of rows.  The flag of the chunk on the left is
+        // polled here (prog[q]; prog[0] belongs to column 0).
+        for (int rb = 0; rb < nblocks; ++rb) {
+            const int r0 = rb * kDfRB, count = min(A.V, r0 + kDfRB) - r0;
+            int poff = 0, np = 0, base = 0, pr[4] = {-1, -1, -1, -1}, ps[4] = {0, 0, 0, 0};
+            if (lane < count) {
+                poff = A.pred_off[r0 + lane]; base = A.base[r0 + lane];
+                np = A.pred_off[r0 + lane + 1] - poff;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { m.pr[x] = -1; m.ps[x] = 0; }
-        if (lane < count) {
-            m.poff = A.pred_off[row0 + lane];
-            m.np = A.pred_off[row0 + lane + 1] - m.poff;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) if (x < m.np) { m.pr[x] = A.pred[m.poff + x]; m.ps[x] = A.pred_slot[m.poff + x]; }
+                for (int x = 0; x < 4; ++x) if (x < np) { pr[x] = A.pred[poff + x]; ps[x] = A.pred_slot[poff + x]; }
+            }
+            if (rb >= 2 && !lds_wait_gt(&taken, rb - 2, P.status, lane)) break;     // the solver has copied block rb-2 out of this slot
+            wait_progress(P.prog + q, rb + 1, P.status, lane);
+            int xin = 0, flag = 1, edge = 0;
+            if (lane < count) {
+                xin = load_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar + q]);
+                flag = load_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar + q]);
+                edge = load_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar + q]);
+            }
+            if (lane < kDfRB) {
+                int (*fb)[kDfRB] = fbuf[rb & 1];
+                fb[FB_POFF][lane] = poff; fb[FB_NP][lane] = np; fb[FB_BASE][lane] = base;
+                fb[FB_PR0][lane] = pr[0]; fb[FB_PR1][lane] = pr[1]; fb[FB_PR2][lane] = pr[2]; fb[FB_PR3][lane] = pr[3];
+                fb[FB_PS0][lane] = ps[0]; fb[FB_PS1][lane] = ps[1]; fb[FB_PS2][lane] = ps[2]; fb[FB_PS3][lane] = ps[3];
+                fb[FB_XIN][lane] = xin; fb[FB_FLAG][lane] = flag; fb[FB_EDGE][lane] = edge;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the LDS performs one wave's operations in order
+            if (lane == 0) __hip_atomic_store(&fetched, rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return m;
-    };
-    struct Left { int xin, flag, edge; };
-    auto load_left = [&](int row0, int count) -> Left {
-        Left l; l.xin = 0; l.flag = 1; l.edge = 0;
-        if (q > 0 && lane < count) {
-            l.xin = load_sc1_int(&A.carry[(size_t)(row0 + lane) * ncar + q]);
-            l.flag = load_sc1_int(&P.cflag32[(size_t)(row0 + lane) * ncar + q]);
-            l.edge = load_sc1_int(&P.edge[(size_t)(row0 + lane) * ncar + q]);
-        }
-        return l;
-    };
-    Meta meta_next; Left left_next; bool have_left_next = false;
-    if (wave == 0) meta_next = load_meta(0, min(A.V, kDfRB));
+        return;
+    }
+    struct Meta { int pr[4], ps[4]; };
     for (int rb = 0; rb < nblocks; ++rb) {
         const int r0 = rb * kDfRB, r1 = min(A.V, r0 + kDfRB), nrows = r1 - r0;
         const int s0 = r0 & (kDfRing - 1);               // ring slot of the block's first row
         const int ring_lo = max(0, r0 - kDfRB);          // oldest row whose record is still in LDS
-        int slot_l = 0, base_l = 0;
-        if (lane < nrows) { slot_l = A.slot[r0 + lane]; base_l = A.base[r0 + lane]; }
 
         if (wave == 0) {
             // ================================================================ solver
-            const Meta mt = meta_next;                        // loaded during the previous block
-            const int poff_l = mt.poff, np_l = mt.np, pfirst_l = mt.pr[0], pfslot_l = mt.ps[0];
+            lds_wait_gt(&fetched, rb, P.status, lane);
+            Meta mt;
+            int poff_l, np_l, base_l, xin_l, flag_l, edge_l;
+            {
+                const int (*fb)[kDfRB] = fbuf[rb & 1];
+                const int l = lane & (kDfRB - 1);
+                poff_l = fb[FB_POFF][l]; np_l = fb[FB_NP][l]; base_l = fb[FB_BASE][l];
+                mt.pr[0] = fb[FB_PR0][l]; mt.pr[1] = fb[FB_PR1][l]; mt.pr[2] = fb[FB_PR2][l]; mt.pr[3] = fb[FB_PR3][l];
+                mt.ps[0] = fb[FB_PS0][l]; mt.ps[1] = fb[FB_PS1][l]; mt.ps[2] = fb[FB_PS2][l]; mt.ps[3] = fb[FB_PS3][l];
+                xin_l = fb[FB_XIN][l]; flag_l = fb[FB_FLAG][l]; edge_l = fb[FB_EDGE][l];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_store(&taken, rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // queued behind the reads
+            const int pfirst_l = mt.pr[0], pfslot_l = mt.ps[0];
             // rows whose only predecessor is the row before them (the first row of a block: the row the previous block ended with)
             const unsigned long long bb_mask = __ballot(lane < nrows && np_l == 1 && pfirst_l == r0 + lane - 1 && (lane > 0 || prev_r == r0 - 1));
             // block rb-2 is complete (all four waves, stores drained): its ring half may be overwritten, and every row older than
             // the ring can be read back from the H / Eagg rows
             if (rb >= 2) lds_wait_gt(&blk_pub, rb - 2, P.status, lane);
-            Left lf = left_next;
-            if (!have_left_next) {
-                if (q > 0) wait_progress(P.prog + q - 1, rb + 1, P.status, lane);       // the chunk on the left has published this block
-                lf = load_left(r0, nrows);
-            }
-            const int xin_l = lf.xin, flag_l = lf.flag, edge_l = lf.edge;
-            // the next block's share, while this one is computed
-            if (rb + 1 < nblocks) {
-                const int nr0 = r0 + kDfRB, ncnt = min(A.V, nr0 + kDfRB) - nr0;
-                meta_next = load_meta(nr0, ncnt);
-                have_left_next = (q == 0) || progress_reached(P.prog + q - 1, rb + 2);
-                if (have_left_next) left_next = load_left(nr0, ncnt);
+            // per-row side data of the block's records, one row per lane: edge H, "first F opens", backbone record or full one
+            if (lane < nrows) {
+                row_edge[s0 + lane] = edge_l; row_flag[s0 + lane] = flag_l;
+                row_kind[s0 + lane] = (lane > 0 && ((bb_mask >> lane) & 1ull)) ? 1 : 0;
             }
             int spread_l = 0;
+            int Mv = M, Xv = X;                               // kept in VGPRs: a select between two SGPRs costs two extra moves per row
+            asm volatile("" : "+v"(Mv), "+v"(Xv));
 
             for (int r = r0; r < r1; ++r) {
                 const int i = r - r0;
@@ -185,30 +257,28 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 const bool backbone = (bb_mask >> i) & 1ull;
                 int sc[kDfKC], a[kDfKC], bq[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
 #pragma unroll
-                for (int k = 0; k < kDfKC; ++k) sc[k] = (sch[k] == bs) ? M : X;
-                int h0 = 0, xin_row, flag_row, my_edge;
+                for (int k = 0; k < kDfKC; ++k) sc[k] = (sch[k] == bs) ? Mv : Xv;
+                const int xin_row = __builtin_amdgcn_readlane(xin_l, i), flag_row = __builtin_amdgcn_readlane(flag_l, i);
+                const int my_edge = __builtin_amdgcn_readlane(edge_l, i);
                 if (backbone) {
                     // ---------------- straight line: H / Eagg of the row above are in registers, its column on the left of
                     // this lane comes by one DPP shift
-                    if (q == 0) { h0 = h0_prev + E; xin_row = h0 + O; flag_row = 1; my_edge = h0; }   // c-t-simd.c:187,194-200
-                    else { xin_row = __builtin_amdgcn_readlane(xin_l, i); flag_row = __builtin_amdgcn_readlane(flag_l, i); my_edge = __builtin_amdgcn_readlane(edge_l, i); }
                     const int hv0 = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
                     bq[0] = hv0 + sc[0]; bq[1] = hs_prev[0] + sc[1];
                     be[0] = max(es_prev[0] + E, hs_prev[0] + OE);                 // c-t-simd.c:524-528
                     be[1] = max(es_prev[1] + E, hs_prev[1] + OE);
                     a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next);
+                    df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
                     {
                         const int si = s0 + i;
-                        rec[F_HS0][si][lane] = hs[0]; rec[F_HS1][si][lane] = hs[1]; rec[F_ES0][si][lane] = be[0]; rec[F_ES1][si][lane] = be[1];
-                        rec[F_FL0][si][lane] = fl[0]; rec[F_FL1][si][lane] = fl[1];
+                        rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
+                        rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1];
                         if (i == 0) {                        // the row above lives in the previous block's records: full record instead
                             const int opn0 = df_shr1(flag_row, opn_next[1]);
                             const unsigned m0 = ((be[0] == hs_prev[0] + OE) ? (64u << 6) : 0u) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
                             const unsigned m1 = ((be[1] == hs_prev[1] + OE) ? (64u << 6) : 0u) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
-                            rec[F_META][si][lane] = (int)(m0 | (m1 << 16));
+                            rec[si][F_META][lane] = (int)(m0 | (m1 << 16));
                         }
-                        if (lane == 0) { row_edge[si] = my_edge; row_h0[si] = h0; row_flag[si] = flag_row; row_kind[si] = (i == 0) ? 0 : 1; }
                     }
                 } else {
                     // ---------------- any other row: virtual init predecessor, several predecessors, a predecessor further back
@@ -223,26 +293,6 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         else { p = A.pred[p0 + j]; ps = A.pred_slot[p0 + j]; }
                     };
                     const bool is_src = (np == 0);           // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
-                    if (q == 0) {                            // first column (c-t-simd.c:187,194-200)
-                        if (is_src) h0 = OE;
-                        else {
-                            h0 = kNeg;
-                            for (int j = 0; j < np; ++j) {
-                                int p, ps;
-                                pred_of(j, p, ps);
-                                int hp;
-                                if (p == prev_r) hp = h0_prev;
-                                else if (p >= ring_lo) hp = row_h0[p & (kDfRing - 1)];
-                                else hp = load_sc1_int(&A.Hrow[(size_t)ps * A.pitch + 3]);
-                                h0 = max(h0, hp);
-                            }
-                            h0 += E;
-                        }
-                        xin_row = h0 + O; flag_row = 1; my_edge = h0;   // F(r,0) = -inf: the first F is an open
-                    } else {
-                        xin_row = __builtin_amdgcn_readlane(xin_l, i); flag_row = __builtin_amdgcn_readlane(flag_l, i);
-                        my_edge = __builtin_amdgcn_readlane(edge_l, i);
-                    }
                     int jq[kDfKC], je[kDfKC];
 #pragma unroll
                     for (int k = 0; k < kDfKC; ++k) { bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0; }
@@ -258,15 +308,15 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         } else if (!is_src && p >= ring_lo) {
                             // a row finished earlier in this block or in the previous one: its record
                             const int ip = p & (kDfRing - 1);
-                            hv[1] = rec[F_HS0][ip][lane]; hv[2] = rec[F_HS1][ip][lane]; ev[0] = rec[F_ES0][ip][lane]; ev[1] = rec[F_ES1][ip][lane];
-                            hv[0] = (lane > 0) ? rec[F_HS1][ip][lane - 1] : row_edge[ip];
+                            hv[1] = rec[ip][F_HS0][lane]; hv[2] = rec[ip][F_HS1][lane]; ev[0] = rec[ip][F_ES0][lane]; ev[1] = rec[ip][F_ES1][lane];
+                            hv[0] = (lane > 0) ? rec[ip][F_HS1][lane - 1] : row_edge[ip];
                         } else {
                             // a row older than the ring (stored by this workgroup's emitters; its block was published before this one began)
                             // or the virtual init row
                             const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
                             const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
                             // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
-                            hv[0] = (lane == 0 && q > 0 && !is_src) ? load_sc1_int(&P.edge[(size_t)p * ncar + q]) : load_sc1_int(Hp);
+                            hv[0] = (lane == 0 && !is_src) ? load_sc1_int(&P.edge[(size_t)p * ncar + q]) : load_sc1_int(Hp);
                             const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
                             const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
                             hv[1] = ha.x; hv[2] = ha.y; ev[0] = ea.x; ev[1] = ea.y;
@@ -286,15 +336,14 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                         for (int k = 0; k < kDfKC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
                     }
                     a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, lane, E, O, aK, w15, w31, hs, fl, opn_next);
+                    df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
                     {
                         const int opn0 = df_shr1(flag_row, opn_next[1]);           // F-open flag of the lane's first column: from the left
                         const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
                         const unsigned m1 = (unsigned)jq[1] | ((unsigned)je[1] << 6) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
                         const int si = s0 + i;
-                        rec[F_HS0][si][lane] = hs[0]; rec[F_HS1][si][lane] = hs[1]; rec[F_ES0][si][lane] = be[0]; rec[F_ES1][si][lane] = be[1];
-                        rec[F_FL0][si][lane] = fl[0]; rec[F_FL1][si][lane] = fl[1]; rec[F_META][si][lane] = (int)(m0 | (m1 << 16));
-                        if (lane == 0) { row_edge[si] = my_edge; row_h0[si] = h0; row_flag[si] = flag_row; row_kind[si] = 0; }
+                        rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
+                        rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1]; rec[si][F_META][lane] = (int)(m0 | (m1 << 16));
                     }
                 }
                 // the counter follows the record: the LDS performs one wave's operations in issue order, so no wait is needed
@@ -303,7 +352,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
-                prev_r = r; h0_prev = h0; edge_prev = my_edge;
+                prev_r = r; edge_prev = my_edge;
             }
             if (__ballot(spread_l > 0)) {
 #pragma unroll
@@ -312,29 +361,31 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
             }
         } else {
             // ================================================================ emitters: rows i = wave-1, wave+2, ...
+            int slot_l = 0, base_l = 0;
+            if (lane < nrows) { slot_l = A.slot[r0 + lane]; base_l = A.base[r0 + lane]; }
             for (int i = wave - 1; i < nrows; i += 3) {
                 if (!lds_wait_gt(&produced, rows_base + i, P.status, lane)) break;
                 const int r = r0 + i, si = s0 + i;
-                const int hs0 = rec[F_HS0][si][lane], hs1 = rec[F_HS1][si][lane], es0 = rec[F_ES0][si][lane], es1 = rec[F_ES1][si][lane];
-                const int fl0 = rec[F_FL0][si][lane], fl1 = rec[F_FL1][si][lane];
+                const int hs0 = rec[si][F_HS0][lane], hs1 = rec[si][F_HS1][lane], es0 = rec[si][F_ES0][lane], es1 = rec[si][F_ES1][lane];
+                const int fl0 = rec[si][F_FL0][lane], fl1 = rec[si][F_FL1][lane];
                 const int myslot = __builtin_amdgcn_readlane(slot_l, i);
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
                 unsigned meta;
                 if (row_kind[si]) {
                     // backbone row: its single predecessor is row i-1 of this block; what the solver did not write is rebuilt
                     // from that row's record (c-t-simd.c:485-506, 524-538, 564-565)
-                    const int ph0 = rec[F_HS0][si - 1][lane], ph1 = rec[F_HS1][si - 1][lane];
-                    const int phl = (lane > 0) ? rec[F_HS1][si - 1][lane - 1] : row_edge[si - 1];      // H(p, column left of this lane)
+                    const int ph0 = rec[si - 1][F_HS0][lane], ph1 = rec[si - 1][F_HS1][lane];
+                    const int phl = (lane > 0) ? rec[si - 1][F_HS1][lane - 1] : row_edge[si - 1];      // H(p, column left of this lane)
                     const int bq0 = phl + ((sch[0] == bs) ? M : X), bq1 = ph0 + ((sch[1] == bs) ? M : X);
                     const int eo0 = ph0 + OE, eo1 = ph1 + OE;
                     // F-open flag of a column: H(c-1) + O >= F(c-1); the lane's first column looks at the lane on the left / the chunk edge
-                    const int opn0 = (lane > 0) ? ((rec[F_HS1][si][lane - 1] + O >= rec[F_FL1][si][lane - 1]) ? 1 : 0) : row_flag[si];
+                    const int opn0 = (lane > 0) ? ((rec[si][F_HS1][lane - 1] + O >= rec[si][F_FL1][lane - 1]) ? 1 : 0) : row_flag[si];
                     const int opn1 = (hs0 + O >= fl0) ? 1 : 0;
                     const unsigned m0 = ((es0 == eo0) ? (64u << 6) : 0u) | ((bq0 == hs0) ? (1u << 13) : 0u) | ((es0 == hs0) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
                     const unsigned m1 = ((es1 == eo1) ? (64u << 6) : 0u) | ((bq1 == hs1) ? (1u << 13) : 0u) | ((es1 == hs1) ? (1u << 14) : 0u) | ((unsigned)opn1 << 15);
                     meta = m0 | (m1 << 16);
                 } else {
-                    meta = (unsigned)rec[F_META][si][lane];
+                    meta = (unsigned)rec[si][F_META][lane];
                 }
                 int* Hr = A.Hrow + (size_t)myslot * A.pitch;
                 int* Er = A.Erow + (size_t)myslot * A.pitch;
@@ -367,7 +418,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
                     }
                     if (c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;         // owner of the last column
                 }
-                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_h0[si]);                      // H(r, 0)
+                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_edge[si]);                    // H(r, 0)
                 if (lane == 63) {                             // what the chunk on the right needs of this row (c-t-simd.c: v0 / f0 carries)
                     store_sc1_int(&A.carry[(size_t)r * ncar + q + 1], max(fl1, hs1 + O));          // Fbar leaving the chunk
                     store_sc1_int(&P.cflag32[(size_t)r * ncar + q + 1], (hs1 + O >= fl1) ? 1 : 0);  // its first F opens from H
@@ -383,7 +434,7 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
             const int before = __hip_atomic_fetch_add(&blk_done[rb & 3], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (before == 3) {
                 __hip_atomic_store(&blk_done[rb & 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store((GlobalI32*)(P.prog + q), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((GlobalI32*)(P.prog + q + 1), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&blk_pub, rb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -392,18 +443,19 @@ __global__ __launch_bounds__(256) void poa_dataflow_kernel(PoaDfArgs P)
 }
 
 // Launches the fill (A complete, inputs uploaded, virtual init row written).  `work` = device ints for this call:
-// [1] status, [16 .. 16+nchunks) blocks of 32 nodes completed per chunk; edge / cflag32 = [V][nchunks+1] ints.
+// [1] status, [16 .. 16+nchunks] blocks of 32 nodes completed by the column-0 solver and by each chunk; edge / cflag32 =
+// [V][nchunks+1] ints.
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_edge, int* d_cflag32, hipStream_t s)
 {
-    const size_t head = 16 + (size_t)A.nchunks;
-    if (head > work_ints || A.nchunks > e->n_cu) return TSTA_ERR_INTERNAL;   // every workgroup must be resident: one per CU
+    const size_t head = 16 + (size_t)A.nchunks + 1;
+    if (head > work_ints || A.nchunks + 1 > e->n_cu) return TSTA_ERR_INTERNAL;   // every workgroup must be resident: one per CU
     int rc;
     if ((rc = e->check(hipMemsetAsync(d_work, 0, head * sizeof(int), s), "hipMemsetAsync(poa dataflow)"))) return rc;
     PoaDfArgs P;
     P.A = A;
     P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
     P.edge = d_edge; P.cflag32 = d_cflag32;
-    hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks + 1), dim3(kDfThreads), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");
 }
 

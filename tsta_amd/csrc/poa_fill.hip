@@ -453,10 +453,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     }
     int num1 = __builtin_amdgcn_readfirstlane(bi >= 0 ? bi : A.V - 1);
     int num2 = A.n - 1, forced = -1, ns = 0;
+    int st_win = 0, st_runs = 0, st_runcells = 0, st_serial = 0;
     if (lane == 0) A.out[2] = num1;
 
     while (num1 != -1 && num2 != -1) {
         // stage the window whose lower-right region holds (num1, num2)
+        ++st_win;
         const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
         {
             const int rr = rw0 + lane;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                         tsta_poa_step st; st.node = r; st.col = c; st.code = (int8_t)code_l; st.peek = (int8_t)pk; st.pad = 0;
                         A.steps[ns + lane] = st;
                     }
-                    ns += run; num1 -= run; num2 -= run;
+                    ns += run; num1 -= run; num2 -= run; ++st_runs; st_runcells += run;
                     continue;
                 }
                 if (__builtin_amdgcn_readfirstlane(have ? 1 : 0)) probed_code = __builtin_amdgcn_readfirstlane(code_l);   // lane 0 probed (num1, num2) itself
@@ -569,12 +571,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 tsta_poa_step st; st.node = num1; st.col = num2; st.code = (int8_t)code; st.peek = (int8_t)peek; st.pad = 0;
                 A.steps[ns] = st;
             }
-            ++ns;
+            ++ns; ++st_serial;
             num1 = n1; num2 = n2;
         }
         __syncthreads();
     }
-    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; }
+    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; A.out[8] = st_win; A.out[9] = st_runs; A.out[10] = st_runcells; A.out[11] = st_serial; }
 }
 
 }  // namespace tsta
@@ -712,7 +714,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
 
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
-    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && nchunks <= e->n_cu && memchr(seq, 'N', (size_t)n) == nullptr;
+    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && nchunks < e->n_cu && memchr(seq, 'N', (size_t)n) == nullptr;
     e->timing_begin(s);
     hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
     int launches = 1;
@@ -802,13 +804,14 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
-    int h_out[5] = {0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
+    int h_out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
     if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
         return rc;
     if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     const int ns = h_out[0];
+    if (getenv("TSTA_WALK_STATS")) fprintf(stderr, "[walk] V=%d n=%d steps=%d windows=%d runs=%d runcells=%d serial=%d\n", V, n, ns, h_out[8], h_out[9], h_out[10], h_out[11]);
     if (ns < 0 || (size_t)ns > cap) { e->set_error("walker returned %d steps", ns); return TSTA_ERR_INTERNAL; }
     tsta_poa_step* out = (tsta_poa_step*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(tsta_poa_step));
     if (!out) return TSTA_ERR_OOM;
