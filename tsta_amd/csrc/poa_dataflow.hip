@@ -53,7 +53,7 @@ __device__ __forceinline__ int df_shr1(int old, int src) { return __builtin_amdg
 __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, int lane)
 {
     int spins = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= v) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~1 s: far beyond any ramp-up of the chunks
         // once any wave of the launch has given up, nobody waits any more
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
     __shared__ int row_edge[kDfRing];                    // H(row, cbase): the column left of the chunk
     __shared__ int row_flag[kDfRing];                    // "F of the chunk's first column opens" of each row
     __shared__ int row_kind[kDfRing];                    // 1: backbone record (no META), 0: full record
-    __shared__ int produced;                             // rows the solver has finished since the kernel began
+    __shared__ int produced[64];                         // rows the solver has finished since the kernel began (64 copies: every lane stores
+                                                         // and polls its own, no exec juggling on the chain of rows)
     __shared__ int blk_done[4];                          // waves (of 4) that have finished block b, slot b & 3
     __shared__ int blk_pub;                              // blocks published (all four waves done, stores drained)
     __shared__ int fbuf[2][FB_COUNT][kDfRB];             // what the fetcher read for block b (slot b & 1), one row per entry
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
     const int ncar = A.nchunks + 1;
     const int cl = lane * aK, cl1 = (lane + 1) * aK;
 
-    if (threadIdx.x == 0) { produced = 0; blk_pub = 0; fetched = 0; taken = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
+    if (threadIdx.x == 0) { blk_pub = 0; fetched = 0; taken = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
+    if (threadIdx.x < 64) produced[threadIdx.x] = 0;
     __syncthreads();
     const int q = blockIdx.x;                            // this workgroup's chunk; workgroup nchunks is the column-0 solver below
     if (q == A.nchunks) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 for (int j = 0; j < np; ++j) {
                     const int p = A.pred[poff + j];
                     if (j < 4) pr[j] = p;
-                    if (p < r0) ext = max(ext, load_sc1_int(&P.edge[(size_t)p * ncar]));
+                    if (p < r0) ext = max(ext, load_sc1_int(&P.hand[((size_t)p * ncar) * 4 + 2]));
                 }
             }
             int h_l = 0;                                 // lane i: H(r0 + i, 0)
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 h_l = (lane == i) ? h : h_l;
             }
             if (lane < nrows) {
-                store_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar], h_l + O);
-                store_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar], 1);
-                store_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar], h_l);
+                int* hd = P.hand + ((size_t)(r0 + lane) * ncar) * 4;
+                store_sc1_int2(reinterpret_cast<int2*>(hd), h_l + O, 1);
+                store_sc1_int2(reinterpret_cast<int2*>(hd + 2), h_l, 0);
             }
             publish_progress(P.prog, rb + 1, lane);
         }
@@ -199,9 +201,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             wait_progress(P.prog + q, rb + 1, P.status, lane);
             int xin = 0, flag = 1, edge = 0;
             if (lane < count) {
-                xin = load_sc1_int(&A.carry[(size_t)(r0 + lane) * ncar + q]);
-                flag = load_sc1_int(&P.cflag32[(size_t)(r0 + lane) * ncar + q]);
-                edge = load_sc1_int(&P.edge[(size_t)(r0 + lane) * ncar + q]);
+                const int* hd = P.hand + ((size_t)(r0 + lane) * ncar + q) * 4;
+                const int2 a = load_sc1_int2(reinterpret_cast<const int2*>(hd)), b = load_sc1_int2(reinterpret_cast<const int2*>(hd + 2));
+                xin = a.x; flag = a.y; edge = b.x;
             }
             if (lane < kDfRB) {
                 int (*fb)[kDfRB] = fbuf[rb & 1];
@@ -251,8 +253,34 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             int Mv = M, Xv = X;                               // kept in VGPRs: a select between two SGPRs costs two extra moves per row
             asm volatile("" : "+v"(Mv), "+v"(Xv));
 
-            for (int r = r0; r < r1; ++r) {
-                const int i = r - r0;
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the staged values are in registers (or the row loop would
+                                                              // wait, at every row, for the LDS writes of the row before)
+            for (int i = 0; i < nrows; ) {
+                const int r = r0 + i;
+                if (i > 0 && ((bb_mask >> i) & 1ull)) {
+                    // ---------------- a run of backbone rows: tight loop, state updated in place, one branch per row
+                    const int i_end = i + __builtin_ctzll(~(bb_mask >> i));
+                    do {
+                        const int bs = __builtin_amdgcn_readlane(base_l, i);
+                        const int xin_row = __builtin_amdgcn_readlane(xin_l, i), my_edge = __builtin_amdgcn_readlane(edge_l, i);
+                        const int sc0 = (sch[0] == bs) ? Mv : Xv, sc1 = (sch[1] == bs) ? Mv : Xv;
+                        int a[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
+                        const int hv0 = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
+                        be[0] = max(es_prev[0] + E, hs_prev[0] + OE);                 // c-t-simd.c:524-528
+                        be[1] = max(es_prev[1] + E, hs_prev[1] + OE);
+                        a[0] = max(hv0 + sc0, be[0]); a[1] = max(hs_prev[0] + sc1, be[1]);
+                        df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
+                        const int si = s0 + i;
+                        rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
+                        rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __hip_atomic_store(&produced[lane], rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1]; edge_prev = my_edge;
+                        ++i;
+                    } while (i < i_end);
+                    prev_r = r0 + i - 1;
+                    continue;
+                }
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
                 const bool backbone = (bb_mask >> i) & 1ull;
                 int sc[kDfKC], a[kDfKC], bq[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                             const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
                             const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
                             // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
-                            hv[0] = (lane == 0 && !is_src) ? load_sc1_int(&P.edge[(size_t)p * ncar + q]) : load_sc1_int(Hp);
+                            hv[0] = (lane == 0 && !is_src) ? load_sc1_int(&P.hand[((size_t)p * ncar + q) * 4 + 2]) : load_sc1_int(Hp);
                             const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
                             const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
                             hv[1] = ha.x; hv[2] = ha.y; ev[0] = ea.x; ev[1] = ea.y;
@@ -350,9 +378,10 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 // here (a workgroup-scope release fence would drain the seven writes first: ~150 cycles on the chain of rows);
                 // the wavefront-scope fence only keeps the compiler from reordering
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (lane == 0) __hip_atomic_store(&produced, rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&produced[lane], rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
                 prev_r = r; edge_prev = my_edge;
+                ++i;
             }
             if (__ballot(spread_l > 0)) {
 #pragma unroll
@@ -361,68 +390,81 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             }
         } else {
             // ================================================================ emitters: rows i = wave-1, wave+2, ...
+            // Written for instruction count (three emitters must keep up with a solver that spends ~55 instructions per
+            // backbone row): wave-uniform row index and row kind (scalar branches, scalar address arithmetic), the values of
+            // the lane on the left by DPP, branch-free selects for the codes.
             int slot_l = 0, base_l = 0;
             if (lane < nrows) { slot_l = A.slot[r0 + lane]; base_l = A.base[r0 + lane]; }
-            for (int i = wave - 1; i < nrows; i += 3) {
-                if (!lds_wait_gt(&produced, rows_base + i, P.status, lane)) break;
-                const int r = r0 + i, si = s0 + i;
+            __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0) here: or every row would wait for the stores of the row before
+            int edge_b = 0, flag_b = 0;
+            unsigned long long kmask = 0;
+            bool have_blk = false;
+            for (int i0 = wave - 1; i0 < nrows; i0 += 3) {
+                const int i = __builtin_amdgcn_readfirstlane(i0);
+                if (!lds_wait_gt(&produced[lane], rows_base + i, P.status, lane)) break;
+                if (!have_blk) {
+                    // the block's side data (the solver wrote them before the block's first record), one row per lane
+                    const int l = s0 + (lane & (kDfRB - 1));
+                    edge_b = row_edge[l]; flag_b = row_flag[l];
+                    kmask = __ballot(row_kind[l] != 0 && lane < kDfRB);
+                    have_blk = true;
+                }
+                const int r = r0 + i, si = s0 + i, sp = max(si - 1, 0);
                 const int hs0 = rec[si][F_HS0][lane], hs1 = rec[si][F_HS1][lane], es0 = rec[si][F_ES0][lane], es1 = rec[si][F_ES1][lane];
                 const int fl0 = rec[si][F_FL0][lane], fl1 = rec[si][F_FL1][lane];
+                const int ph0 = rec[sp][F_HS0][lane], ph1 = rec[sp][F_HS1][lane];          // the row above (used by backbone rows)
+                const unsigned metaw = (unsigned)rec[si][F_META][lane];                    // (used by the other rows)
                 const int myslot = __builtin_amdgcn_readlane(slot_l, i);
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
-                unsigned meta;
-                if (row_kind[si]) {
+                const bool mt0 = (sch[0] == bs), mt1 = (sch[1] == bs);
+                const int hO0 = hs0 + O, hO1 = hs1 + O, hOE0 = hO0 + E, hOE1 = hO1 + E;
+                int code0, code1, ep0, ep1, opn0, opn1;
+                if ((kmask >> i) & 1ull) {
                     // backbone row: its single predecessor is row i-1 of this block; what the solver did not write is rebuilt
                     // from that row's record (c-t-simd.c:485-506, 524-538, 564-565)
-                    const int ph0 = rec[si - 1][F_HS0][lane], ph1 = rec[si - 1][F_HS1][lane];
-                    const int phl = (lane > 0) ? rec[si - 1][F_HS1][lane - 1] : row_edge[si - 1];      // H(p, column left of this lane)
-                    const int bq0 = phl + ((sch[0] == bs) ? M : X), bq1 = ph0 + ((sch[1] == bs) ? M : X);
-                    const int eo0 = ph0 + OE, eo1 = ph1 + OE;
+                    const int edge_p = __builtin_amdgcn_readlane(edge_b, i - 1), flag_r = __builtin_amdgcn_readlane(flag_b, i);
+                    const int phl = df_shr1(edge_p, ph1);                                  // H(p, column left of this lane)
+                    const int bq0 = phl + (mt0 ? M : X), bq1 = ph0 + (mt1 ? M : X);
                     // F-open flag of a column: H(c-1) + O >= F(c-1); the lane's first column looks at the lane on the left / the chunk edge
-                    const int opn0 = (lane > 0) ? ((rec[si][F_HS1][lane - 1] + O >= rec[si][F_FL1][lane - 1]) ? 1 : 0) : row_flag[si];
-                    const int opn1 = (hs0 + O >= fl0) ? 1 : 0;
-                    const unsigned m0 = ((es0 == eo0) ? (64u << 6) : 0u) | ((bq0 == hs0) ? (1u << 13) : 0u) | ((es0 == hs0) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
-                    const unsigned m1 = ((es1 == eo1) ? (64u << 6) : 0u) | ((bq1 == hs1) ? (1u << 13) : 0u) | ((es1 == hs1) ? (1u << 14) : 0u) | ((unsigned)opn1 << 15);
-                    meta = m0 | (m1 << 16);
+                    opn1 = (hO0 >= fl0) ? 1 : 0;
+                    opn0 = df_shr1(flag_r, (hO1 >= fl1) ? 1 : 0);
+                    code0 = (bq0 == hs0) ? (mt0 ? 42 : 84) : ((es0 == hs0) ? 0 : 126);   // match > mismatch > E > F (c-t-simd.c:485-506)
+                    code1 = (bq1 == hs1) ? (mt1 ? 42 : 84) : ((es1 == hs1) ? 0 : 126);
+                    ep0 = (es0 == ph0 + OE) ? 43 : 1;                                      // c-t-simd.c:530-538
+                    ep1 = (es1 == ph1 + OE) ? 43 : 1;
                 } else {
-                    meta = (unsigned)rec[si][F_META][lane];
+                    const int m0 = (int)(metaw & 0xffffu), m1 = (int)(metaw >> 16);
+                    const int je0 = (m0 >> 6) & 127, je1 = (m1 >> 6) & 127;
+                    code0 = (m0 & (1 << 13)) ? (mt0 ? 42 : 84) + (m0 & 63) : ((m0 & (1 << 14)) ? (je0 & 63) : 126);
+                    code1 = (m1 & (1 << 13)) ? (mt1 ? 42 : 84) + (m1 & 63) : ((m1 & (1 << 14)) ? (je1 & 63) : 126);
+                    ep0 = ((je0 & 64) ? 43 : 1) + (je0 & 63);
+                    ep1 = ((je1 & 64) ? 43 : 1) + (je1 & 63);
+                    opn0 = (m0 >> 15) & 1; opn1 = (m1 >> 15) & 1;
                 }
+                const int ec0 = (es0 + E == hOE0) ? -ep0 : ep0, ec1 = (es1 + E == hOE1) ? -ep1 : ep1;
+                const int fp0 = opn0 + 1, fp1 = opn1 + 1;                                   // c-t-simd.c:521-522,564-565
+                const int fc0 = (fl0 + E == hOE0) ? -fp0 : fp0, fc1 = (fl1 + E == hOE1) ? -fp1 : fp1;
+                const unsigned w1 = (unsigned)(code0 & 0xff) | ((unsigned)(code1 & 0xff) << 8);
+                const unsigned w2 = (unsigned)(ec0 & 0xff) | ((unsigned)(ec1 & 0xff) << 8);
+                const unsigned w3 = (unsigned)(fc0 & 0xff) | ((unsigned)(fc1 & 0xff) << 8);
                 int* Hr = A.Hrow + (size_t)myslot * A.pitch;
                 int* Er = A.Erow + (size_t)myslot * A.pitch;
                 if (c0 < n) {
-                    unsigned w1 = 0, w2 = 0, w3 = 0;
-#pragma unroll
-                    for (int k = 0; k < kDfKC; ++k) {
-                        const int h = k ? hs1 : hs0, f = k ? fl1 : fl0, be = k ? es1 : es0;
-                        const int m = (int)((meta >> (16 * k)) & 0xffffu);
-                        const int jq = m & 63, je = (m >> 6) & 127;
-                        const bool mt = (sch[k] == bs);
-                        int code;                            // match > mismatch > E > F (c-t-simd.c:485-506)
-                        if (m & (1 << 13)) code = (mt ? 42 : 84) + jq;
-                        else if (m & (1 << 14)) code = je & 63;
-                        else code = 126;
-                        int ecode = ((je & 64) ? 43 : 1) + (je & 63);              // c-t-simd.c:530-538
-                        if (be + E == h + OE) ecode = -ecode;
-                        int fcode = (m & (1 << 15)) ? 2 : 1;                       // c-t-simd.c:521-522,564-565
-                        if (f + E == h + OE) fcode = -fcode;
-                        w1 |= (unsigned)(uint8_t)code << (8 * k);
-                        w2 |= (unsigned)(uint8_t)ecode << (8 * k);
-                        w3 |= (unsigned)(uint8_t)fcode << (8 * k);
-                    }
                     store_sc1_int2(reinterpret_cast<int2*>(Hr + c0 + 4), hs0, hs1);              // H(r, c0+1..c0+2): read by later blocks of this launch
                     store_sc1_int2(reinterpret_cast<int2*>(Er + c0), es0, es1);
                     if (A.source) {                                                           // trace: read after the launch only
-                        *reinterpret_cast<unsigned short*>(A.source + (size_t)r * A.tpitch + c0) = (unsigned short)w1;
-                        *reinterpret_cast<unsigned short*>(A.esource + (size_t)r * A.tpitch + c0) = (unsigned short)w2;
-                        *reinterpret_cast<unsigned short*>(A.fsource + (size_t)r * A.tpitch + c0) = (unsigned short)w3;
+                        const size_t toff = (size_t)r * A.tpitch;
+                        *reinterpret_cast<unsigned short*>(A.source + toff + c0) = (unsigned short)w1;
+                        *reinterpret_cast<unsigned short*>(A.esource + toff + c0) = (unsigned short)w2;
+                        *reinterpret_cast<unsigned short*>(A.fsource + toff + c0) = (unsigned short)w3;
                     }
-                    if (c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;         // owner of the last column
                 }
-                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], row_edge[si]);                    // H(r, 0)
+                if (q == A.nchunks - 1 && c0 < n && c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;   // owner of the last column
+                if (q == 0 && lane == 0) store_sc1_int(&Hr[3], __builtin_amdgcn_readlane(edge_b, i));      // H(r, 0)
                 if (lane == 63) {                             // what the chunk on the right needs of this row (c-t-simd.c: v0 / f0 carries)
-                    store_sc1_int(&A.carry[(size_t)r * ncar + q + 1], max(fl1, hs1 + O));          // Fbar leaving the chunk
-                    store_sc1_int(&P.cflag32[(size_t)r * ncar + q + 1], (hs1 + O >= fl1) ? 1 : 0);  // its first F opens from H
-                    store_sc1_int(&P.edge[(size_t)r * ncar + q + 1], hs1);                         // H at the chunk's right edge
+                    int* hd = P.hand + ((size_t)r * ncar + q + 1) * 4;
+                    store_sc1_int2(reinterpret_cast<int2*>(hd), max(fl1, hO1), (hO1 >= fl1) ? 1 : 0);   // Fbar leaving the chunk; its first F opens from H
+                    store_sc1_int2(reinterpret_cast<int2*>(hd + 2), hs1, 0);                            // H at the chunk's right edge
                 }
             }
         }
@@ -443,9 +485,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 }
 
 // Launches the fill (A complete, inputs uploaded, virtual init row written).  `work` = device ints for this call:
-// [1] status, [16 .. 16+nchunks] blocks of 32 nodes completed by the column-0 solver and by each chunk; edge / cflag32 =
-// [V][nchunks+1] ints.
-int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_edge, int* d_cflag32, hipStream_t s)
+// [1] status, [16 .. 16+nchunks] blocks of 32 nodes completed by the column-0 solver and by each chunk; hand =
+// [V][nchunks+1][4] ints.
+int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s)
 {
     const size_t head = 16 + (size_t)A.nchunks + 1;
     if (head > work_ints || A.nchunks + 1 > e->n_cu) return TSTA_ERR_INTERNAL;   // every workgroup must be resident: one per CU
@@ -454,7 +496,7 @@ int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_in
     PoaDfArgs P;
     P.A = A;
     P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
-    P.edge = d_edge; P.cflag32 = d_cflag32;
+    P.hand = d_hand;
     hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks + 1), dim3(kDfThreads), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");
 }

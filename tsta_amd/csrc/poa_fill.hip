@@ -673,7 +673,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)", true)) ||
         (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)", true)) ||
         (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)", true)) ||
-        (rc = e->reserve(e->scratch, 3 * (size_t)V * (nchunks + 1) * 4 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)", true)) ||
+        (rc = e->reserve(e->scratch, 5 * (size_t)V * (nchunks + 1) * 4 + 64 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)", true)) ||
         (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)", true)))
         return rc;
     if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)", true))) return rc;
@@ -720,11 +720,10 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     int launches = 1;
     if (dataflow) {
         const size_t per = (size_t)V * (nchunks + 1);
-        int* d_edge = A.carry + per;
-        int* d_cflag32 = d_edge + per;
-        int* d_work = d_cflag32 + per;
+        int* d_hand = A.carry + ((per + 3) & ~(size_t)3);    // [V][nchunks+1][4], 16-byte aligned
+        int* d_work = d_hand + 4 * per;
         const size_t work_ints = (size_t)2 * (nchunks + nrb) + nchunks + 64;
-        if ((rc = launch_poa_dataflow(e, A, d_work, work_ints, d_edge, d_cflag32, s)) != TSTA_OK) return rc;
+        if ((rc = launch_poa_dataflow(e, A, d_work, work_ints, d_hand, s)) != TSTA_OK) return rc;
         hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
         e->n_launches = 3;
         e->poa_status = reinterpret_cast<unsigned*>(d_work + 1);

@@ -38,11 +38,11 @@ struct PoaArgs {
 struct PoaDfArgs {
     PoaArgs A;
     unsigned* status;
-    int* prog;                           // [nchunks]: blocks of 64 nodes completed in chunk q
-    int* edge;                           // [V][nchunks+1]: H(r, last column of chunk q-1), i.e. the column left of chunk q
-    int* cflag32;                        // [V][nchunks+1]: as PoaArgs::cflag, one int each (sc1 dword hand-off)
+    int* prog;                           // [nchunks+1]: blocks of 32 nodes completed by the column-0 solver ([0]) and by chunk q ([q+1])
+    int* hand;                           // [V][nchunks+1][4]: what chunk q takes over from the chunk on its left for row r: {F carry
+                                         // entering the chunk, "its first F is an open", H(r, column left of the chunk), unused} (sc1 hand-off)
 };
-int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_edge, int* d_cflag32, hipStream_t s);
+int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s);
 
 void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
 void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
