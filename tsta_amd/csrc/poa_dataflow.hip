@@ -35,14 +35,17 @@ constexpr int kDfKC = 2;                 // columns per lane
 constexpr int kDfCW = 64 * kDfKC;        // columns per chunk
 constexpr int kDfRB = 32;                // nodes per block
 constexpr int kDfThreads = 320;           // solver, three emitters, fetcher
-constexpr int kDfRing = 2 * kDfRB;       // rows whose records stay in LDS: this block and the one before (7 x 64 x 64 ints = 112 KB)
+constexpr int kDfRing = 3 * kDfRB;       // rows whose records stay in LDS: three blocks (the solver writes one and reads the one before it,
+                                         // the emitters of that one still read the third): 96 x 6 x 64 ints = 144 KB
 
 // What the solver leaves per lane and row in LDS (rec[row][field][lane]: every access is 64 consecutive dwords,
-// conflict-free; the fields of a row are reached from one address).  A BACKBONE row (one predecessor = the row before it, not the first row of a block) gets only
-// H, Eagg and F: everything else a trace code needs, the emitter recomputes from the record of the row above.  Any other
-// row also gets META: per column (16 bits each) jq | je(7 bits, bit 6 = "opened") << 6 | (bq==H) << 13 | (be==H) << 14 |
-// F-open flag << 15.
-enum { F_HS0, F_HS1, F_ES0, F_ES1, F_FL0, F_FL1, F_META, F_COUNT };
+// conflict-free; the fields of a row are reached from one address): H, Eagg and F of the lane's two columns — only what the
+// NEXT rows need.  Everything else a trace code records (which predecessor won, whether a gap opened) the emitters work out
+// again from the records of the row's predecessors.
+enum { F_HS0, F_HS1, F_ES0, F_ES1, F_FL0, F_FL1, F_COUNT };
+// Per-row side data next to the records (side[what][row slot]): H left of the chunk, "first F opens", and the row's
+// predecessor list for the emitters (number, offset, the first four with their row slots).
+enum { S_EDGE, S_FLAG, S_NP, S_POFF, S_PR0, S_PR1, S_PR2, S_PR3, S_PS0, S_PS1, S_PS2, S_PS3, S_COUNT };
 // What the fetcher wave stages per row of a block: the DAG metadata (offset / number of predecessors, the first four of them
 // with their row slots, the node's base) and what the chunk on the left handed over (F carry, open flag, edge H).
 enum { FB_POFF, FB_NP, FB_PR0, FB_PR1, FB_PR2, FB_PR3, FB_PS0, FB_PS1, FB_PS2, FB_PS3, FB_BASE, FB_XIN, FB_FLAG, FB_EDGE, FB_COUNT };
@@ -104,10 +107,8 @@ __device__ __forceinline__ void df_scan_row(const int (&a)[kDfKC], int xin_row, 
 __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 {
     const PoaArgs& A = P.A;
-    __shared__ int rec[kDfRing][F_COUNT][64];            // 112 KB, row r in slot r % 64
-    __shared__ int row_edge[kDfRing];                    // H(row, cbase): the column left of the chunk
-    __shared__ int row_flag[kDfRing];                    // "F of the chunk's first column opens" of each row
-    __shared__ int row_kind[kDfRing];                    // 1: backbone record (no META), 0: full record
+    __shared__ int rec[kDfRing][F_COUNT][64];            // 144 KB, block b in slots (b % 3) * 32 ..
+    __shared__ int side[S_COUNT][kDfRing];
     __shared__ int produced[64];                         // rows the solver has finished since the kernel began (64 copies: every lane stores
                                                          // and polls its own, no exec juggling on the chain of rows)
     __shared__ int blk_done[4];                          // waves (of 4) that have finished block b, slot b & 3
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
     __shared__ int fbuf[2][FB_COUNT][kDfRB];             // what the fetcher read for block b (slot b & 1), one row per entry
     __shared__ int fetched;                              // blocks the fetcher has put into fbuf
     __shared__ int taken;                                // blocks the solver has copied out of fbuf
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the roles' loops stay uniform)
     const int n = A.n, M = A.M, X = A.X, E = A.E, O = A.O, OE = A.O + A.E;
     const int aK = kDfKC * E;
     const int ncar = A.nchunks + 1;
@@ -217,48 +218,66 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
         }
         return;
     }
-    struct Meta { int pr[4], ps[4]; };
-    for (int rb = 0; rb < nblocks; ++rb) {
+    // One predecessor row as a lane sees it: H at the column left of the lane's first column, H and Eagg at its two columns.
+    struct PredVals { int hl, h0, h1, e0, e1; };
+    // ... from global memory: a row older than the ring (stored by this workgroup's emitters; its block was published before
+    // the reader's block began), or the virtual init row (slot 0) of a source node
+    auto pred_far = [&](int p, int ps, bool is_src) -> PredVals {
+        const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
+        const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
+        PredVals v;
+        // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
+        v.hl = (lane == 0 && !is_src) ? load_sc1_int(&P.hand[((size_t)p * ncar + q) * 4 + 2]) : load_sc1_int(Hp);
+        const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
+        const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
+        v.h0 = ha.x; v.h1 = ha.y; v.e0 = ea.x; v.e1 = ea.y;
+        return v;
+    };
+    int blk3 = 0;                                        // rb % 3
+    for (int rb = 0; rb < nblocks; ++rb, blk3 = (blk3 == 2 ? 0 : blk3 + 1)) {
         const int r0 = rb * kDfRB, r1 = min(A.V, r0 + kDfRB), nrows = r1 - r0;
-        const int s0 = r0 & (kDfRing - 1);               // ring slot of the block's first row
-        const int ring_lo = max(0, r0 - kDfRB);          // oldest row whose record is still in LDS
+        const int s0 = blk3 * kDfRB;                     // ring slot of the block's first row
+        const int sprev = (blk3 == 0 ? 2 : blk3 - 1) * kDfRB;   // ... of the previous block's first row
+        const int ring_lo = max(0, r0 - kDfRB);          // oldest row a row of this block reads from the ring
+        auto ring_slot = [&](int p) -> int { return (p >= r0 ? s0 : sprev) + (p & (kDfRB - 1)); };
 
         if (wave == 0) {
             // ================================================================ solver
             lds_wait_gt(&fetched, rb, P.status, lane);
-            Meta mt;
-            int poff_l, np_l, base_l, xin_l, flag_l, edge_l;
+            int poff_l, np_l, base_l, xin_l, flag_l, edge_l, pr_l[4], ps_l[4];
             {
                 const int (*fb)[kDfRB] = fbuf[rb & 1];
                 const int l = lane & (kDfRB - 1);
                 poff_l = fb[FB_POFF][l]; np_l = fb[FB_NP][l]; base_l = fb[FB_BASE][l];
-                mt.pr[0] = fb[FB_PR0][l]; mt.pr[1] = fb[FB_PR1][l]; mt.pr[2] = fb[FB_PR2][l]; mt.pr[3] = fb[FB_PR3][l];
-                mt.ps[0] = fb[FB_PS0][l]; mt.ps[1] = fb[FB_PS1][l]; mt.ps[2] = fb[FB_PS2][l]; mt.ps[3] = fb[FB_PS3][l];
+                pr_l[0] = fb[FB_PR0][l]; pr_l[1] = fb[FB_PR1][l]; pr_l[2] = fb[FB_PR2][l]; pr_l[3] = fb[FB_PR3][l];
+                ps_l[0] = fb[FB_PS0][l]; ps_l[1] = fb[FB_PS1][l]; ps_l[2] = fb[FB_PS2][l]; ps_l[3] = fb[FB_PS3][l];
                 xin_l = fb[FB_XIN][l]; flag_l = fb[FB_FLAG][l]; edge_l = fb[FB_EDGE][l];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) __hip_atomic_store(&taken, rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // queued behind the reads
-            const int pfirst_l = mt.pr[0], pfslot_l = mt.ps[0];
             // rows whose only predecessor is the row before them (the first row of a block: the row the previous block ended with)
-            const unsigned long long bb_mask = __ballot(lane < nrows && np_l == 1 && pfirst_l == r0 + lane - 1 && (lane > 0 || prev_r == r0 - 1));
-            // block rb-2 is complete (all four waves, stores drained): its ring half may be overwritten, and every row older than
-            // the ring can be read back from the H / Eagg rows
+            const unsigned long long bb_mask = __ballot(lane < nrows && np_l == 1 && pr_l[0] == r0 + lane - 1 && (lane > 0 || prev_r == r0 - 1));
+            // rows all of whose (at most four) predecessors have their records in the ring
+            const unsigned long long near_mask = __ballot(lane < nrows && np_l >= 1 && np_l <= 4 && pr_l[0] >= ring_lo &&
+                                                          (np_l < 2 || pr_l[1] >= ring_lo) && (np_l < 3 || pr_l[2] >= ring_lo) && (np_l < 4 || pr_l[3] >= ring_lo));
+            // blocks rb-3 and rb-2 are complete (all four waves, stores drained): the ring third of block rb-3 may be overwritten
+            // (nobody reads it any more), and every row older than the ring can be read back from the H / Eagg rows
             if (rb >= 2) lds_wait_gt(&blk_pub, rb - 2, P.status, lane);
-            // per-row side data of the block's records, one row per lane: edge H, "first F opens", backbone record or full one
-            if (lane < nrows) {
-                row_edge[s0 + lane] = edge_l; row_flag[s0 + lane] = flag_l;
-                row_kind[s0 + lane] = (lane > 0 && ((bb_mask >> lane) & 1ull)) ? 1 : 0;
+            // per-row side data of the block's records, one row per lane
+            if (lane < kDfRB) {
+                const int sl = s0 + lane;
+                side[S_EDGE][sl] = edge_l; side[S_FLAG][sl] = flag_l; side[S_NP][sl] = np_l; side[S_POFF][sl] = poff_l;
+                side[S_PR0][sl] = pr_l[0]; side[S_PR1][sl] = pr_l[1]; side[S_PR2][sl] = pr_l[2]; side[S_PR3][sl] = pr_l[3];
+                side[S_PS0][sl] = ps_l[0]; side[S_PS1][sl] = ps_l[1]; side[S_PS2][sl] = ps_l[2]; side[S_PS3][sl] = ps_l[3];
             }
-            int spread_l = 0;
             int Mv = M, Xv = X;                               // kept in VGPRs: a select between two SGPRs costs two extra moves per row
             asm volatile("" : "+v"(Mv), "+v"(Xv));
-
             __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the staged values are in registers (or the row loop would
                                                               // wait, at every row, for the LDS writes of the row before)
             for (int i = 0; i < nrows; ) {
-                const int r = r0 + i;
-                if (i > 0 && ((bb_mask >> i) & 1ull)) {
-                    // ---------------- a run of backbone rows: tight loop, state updated in place, one branch per row
+                if ((bb_mask >> i) & 1ull) {
+                    // ---------------- a run of backbone rows: H / Eagg of the row above are in registers, its column on the left
+                    // of this lane comes by one DPP shift; tight loop, state updated in place, one branch per row
                     const int i_end = i + __builtin_ctzll(~(bb_mask >> i));
                     do {
                         const int bs = __builtin_amdgcn_readlane(base_l, i);
@@ -273,6 +292,8 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                         const int si = s0 + i;
                         rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
                         rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1];
+                        // the counter follows the record: the LDS performs one wave's operations in issue order, so no wait is
+                        // needed (a workgroup-scope release fence would drain the writes first: ~150 cycles on the chain of rows)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __hip_atomic_store(&produced[lane], rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1]; edge_prev = my_edge;
@@ -281,166 +302,177 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                     prev_r = r0 + i - 1;
                     continue;
                 }
+                // ---------------- any other row: the maxima over its predecessors (values only)
+                const int r = r0 + i;
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
-                const bool backbone = (bb_mask >> i) & 1ull;
-                int sc[kDfKC], a[kDfKC], bq[kDfKC], be[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
-#pragma unroll
-                for (int k = 0; k < kDfKC; ++k) sc[k] = (sch[k] == bs) ? Mv : Xv;
-                const int xin_row = __builtin_amdgcn_readlane(xin_l, i), flag_row = __builtin_amdgcn_readlane(flag_l, i);
-                const int my_edge = __builtin_amdgcn_readlane(edge_l, i);
-                if (backbone) {
-                    // ---------------- straight line: H / Eagg of the row above are in registers, its column on the left of
-                    // this lane comes by one DPP shift
-                    const int hv0 = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
-                    bq[0] = hv0 + sc[0]; bq[1] = hs_prev[0] + sc[1];
-                    be[0] = max(es_prev[0] + E, hs_prev[0] + OE);                 // c-t-simd.c:524-528
-                    be[1] = max(es_prev[1] + E, hs_prev[1] + OE);
-                    a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
-                    {
-                        const int si = s0 + i;
-                        rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
-                        rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1];
-                        if (i == 0) {                        // the row above lives in the previous block's records: full record instead
-                            const int opn0 = df_shr1(flag_row, opn_next[1]);
-                            const unsigned m0 = ((be[0] == hs_prev[0] + OE) ? (64u << 6) : 0u) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
-                            const unsigned m1 = ((be[1] == hs_prev[1] + OE) ? (64u << 6) : 0u) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
-                            rec[si][F_META][lane] = (int)(m0 | (m1 << 16));
+                const int xin_row = __builtin_amdgcn_readlane(xin_l, i), my_edge = __builtin_amdgcn_readlane(edge_l, i);
+                const int sc0 = (sch[0] == bs) ? Mv : Xv, sc1 = (sch[1] == bs) ? Mv : Xv;
+                const int np = __builtin_amdgcn_readlane(np_l, i);
+                int bq0 = kNeg, bq1 = kNeg, be0 = kNeg, be1 = kNeg;
+                if ((near_mask >> i) & 1ull) {
+                    // every predecessor's record is in the ring: the reads of the first two go out together, one wait
+                    PredVals va, vb;
+                    int eda, edb = 0;
+                    { const int sl = ring_slot(__builtin_amdgcn_readlane(pr_l[0], i));
+                      va.h0 = rec[sl][F_HS0][lane]; va.h1 = rec[sl][F_HS1][lane]; va.e0 = rec[sl][F_ES0][lane]; va.e1 = rec[sl][F_ES1][lane]; eda = side[S_EDGE][sl]; }
+                    if (np > 1) {
+                        const int sl = ring_slot(__builtin_amdgcn_readlane(pr_l[1], i));
+                        vb.h0 = rec[sl][F_HS0][lane]; vb.h1 = rec[sl][F_HS1][lane]; vb.e0 = rec[sl][F_ES0][lane]; vb.e1 = rec[sl][F_ES1][lane]; edb = side[S_EDGE][sl];
+                    }
+                    bq0 = df_shr1(eda, va.h1) + sc0; bq1 = va.h0 + sc1;
+                    be0 = max(va.e0 + E, va.h0 + OE); be1 = max(va.e1 + E, va.h1 + OE);   // c-t-simd.c:524-528
+                    if (np > 1) {
+                        bq0 = max(bq0, df_shr1(edb, vb.h1) + sc0); bq1 = max(bq1, vb.h0 + sc1);
+                        be0 = max(be0, max(vb.e0 + E, vb.h0 + OE)); be1 = max(be1, max(vb.e1 + E, vb.h1 + OE));
+                        for (int j = 2; j < np; ++j) {
+                            const int sl = ring_slot(j == 2 ? __builtin_amdgcn_readlane(pr_l[2], i) : __builtin_amdgcn_readlane(pr_l[3], i));
+                            const int h0 = rec[sl][F_HS0][lane], h1 = rec[sl][F_HS1][lane], e0 = rec[sl][F_ES0][lane], e1 = rec[sl][F_ES1][lane];
+                            bq0 = max(bq0, df_shr1(side[S_EDGE][sl], h1) + sc0); bq1 = max(bq1, h0 + sc1);
+                            be0 = max(be0, max(e0 + E, h0 + OE)); be1 = max(be1, max(e1 + E, h1 + OE));
                         }
                     }
                 } else {
-                    // ---------------- any other row: virtual init predecessor, several predecessors, a predecessor further back
-                    const int p0 = __builtin_amdgcn_readlane(poff_l, i), np = __builtin_amdgcn_readlane(np_l, i);
-                    const int pfirst = __builtin_amdgcn_readlane(pfirst_l, i), pfslot = __builtin_amdgcn_readlane(pfslot_l, i);
-                    // predecessor j of this row and its row slot: the first four travel in lanes, the rest is read from memory
-                    auto pred_of = [&](int j, int& p, int& ps) {
-                        if (j == 0) { p = pfirst; ps = pfslot; }
-                        else if (j == 1) { p = __builtin_amdgcn_readlane(mt.pr[1], i); ps = __builtin_amdgcn_readlane(mt.ps[1], i); }
-                        else if (j == 2) { p = __builtin_amdgcn_readlane(mt.pr[2], i); ps = __builtin_amdgcn_readlane(mt.ps[2], i); }
-                        else if (j == 3) { p = __builtin_amdgcn_readlane(mt.pr[3], i); ps = __builtin_amdgcn_readlane(mt.ps[3], i); }
-                        else { p = A.pred[p0 + j]; ps = A.pred_slot[p0 + j]; }
-                    };
-                    const bool is_src = (np == 0);           // in==0 -> virtual init predecessor (c-t-simd.c:174-188)
-                    int jq[kDfKC], je[kDfKC];
-#pragma unroll
-                    for (int k = 0; k < kDfKC; ++k) { bq[k] = kNeg; jq[k] = 0; be[k] = kNeg; je[k] = 0; }
+                    // a source (virtual init predecessor, c-t-simd.c:174-188), a predecessor older than the ring, more than four
+                    const bool is_src = (np == 0);
+                    const int p0 = __builtin_amdgcn_readlane(poff_l, i);
                     const int npp = is_src ? 1 : np;
-                    int hmx[kDfKC] = {kNeg, kNeg}, hmn[kDfKC] = {-kNeg, -kNeg};
                     for (int j = 0; j < npp; ++j) {
                         int p = A.V, ps = 0;
-                        if (!is_src) pred_of(j, p, ps);
-                        int hv[kDfKC + 1], ev[kDfKC];
-                        if (p == prev_r) {
-                            hv[0] = df_shr1(edge_prev, hs_prev[kDfKC - 1]);
-                            hv[1] = hs_prev[0]; hv[2] = hs_prev[1]; ev[0] = es_prev[0]; ev[1] = es_prev[1];
-                        } else if (!is_src && p >= ring_lo) {
-                            // a row finished earlier in this block or in the previous one: its record
-                            const int ip = p & (kDfRing - 1);
-                            hv[1] = rec[ip][F_HS0][lane]; hv[2] = rec[ip][F_HS1][lane]; ev[0] = rec[ip][F_ES0][lane]; ev[1] = rec[ip][F_ES1][lane];
-                            hv[0] = (lane > 0) ? rec[ip][F_HS1][lane - 1] : row_edge[ip];
+                        if (!is_src) {
+                            if (j == 0) { p = __builtin_amdgcn_readlane(pr_l[0], i); ps = __builtin_amdgcn_readlane(ps_l[0], i); }
+                            else if (j == 1) { p = __builtin_amdgcn_readlane(pr_l[1], i); ps = __builtin_amdgcn_readlane(ps_l[1], i); }
+                            else if (j == 2) { p = __builtin_amdgcn_readlane(pr_l[2], i); ps = __builtin_amdgcn_readlane(ps_l[2], i); }
+                            else if (j == 3) { p = __builtin_amdgcn_readlane(pr_l[3], i); ps = __builtin_amdgcn_readlane(ps_l[3], i); }
+                            else { p = __builtin_amdgcn_readfirstlane(A.pred[p0 + j]); ps = __builtin_amdgcn_readfirstlane(A.pred_slot[p0 + j]); }
+                        }
+                        PredVals v;
+                        if (!is_src && p >= ring_lo) {
+                            const int sl = ring_slot(p);
+                            v.h0 = rec[sl][F_HS0][lane]; v.h1 = rec[sl][F_HS1][lane]; v.e0 = rec[sl][F_ES0][lane]; v.e1 = rec[sl][F_ES1][lane];
+                            v.hl = df_shr1(side[S_EDGE][sl], v.h1);
                         } else {
-                            // a row older than the ring (stored by this workgroup's emitters; its block was published before this one began)
-                            // or the virtual init row
-                            const int* Hp = A.Hrow + (size_t)ps * A.pitch + c0 + 3;    // H(p, c0 .. c0+2)
-                            const int* Ep = A.Erow + (size_t)ps * A.pitch + c0;        // Eagg(p, c0+1 .. c0+2)
-                            // the column left of the chunk belongs to the chunk on the left: its per-(row, chunk) copy
-                            hv[0] = (lane == 0 && !is_src) ? load_sc1_int(&P.hand[((size_t)p * ncar + q) * 4 + 2]) : load_sc1_int(Hp);
-                            const int2 ha = load_sc1_int2(reinterpret_cast<const int2*>(Hp + 1));
-                            const int2 ea = load_sc1_int2(reinterpret_cast<const int2*>(Ep));
-                            hv[1] = ha.x; hv[2] = ha.y; ev[0] = ea.x; ev[1] = ea.y;
+                            v = pred_far(p, ps, is_src);
                         }
-#pragma unroll
-                        for (int k = 0; k < kDfKC; ++k) {
-                            const int qv = hv[k] + sc[k];                          // diagonal from H(p, c-1)
-                            if (qv > bq[k]) { bq[k] = qv; jq[k] = j; }             // lowest predecessor index on ties
-                            const int eo = hv[k + 1] + OE, ex = ev[k] + E;         // c-t-simd.c:524-528
-                            const int ein = max(ex, eo);
-                            if (ein > be[k]) { be[k] = ein; je[k] = j | ((ein == eo) ? 64 : 0); }
-                            if (npp > 1) { hmx[k] = max(hmx[k], hv[k + 1]); hmn[k] = min(hmn[k], hv[k + 1]); }
-                        }
-                    }
-                    if (npp > 1) {
-#pragma unroll
-                        for (int k = 0; k < kDfKC; ++k) if (c0 + k < n) spread_l = max(spread_l, hmx[k] - hmn[k]);
-                    }
-                    a[0] = max(bq[0], be[0]); a[1] = max(bq[1], be[1]);
-                    df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
-                    {
-                        const int opn0 = df_shr1(flag_row, opn_next[1]);           // F-open flag of the lane's first column: from the left
-                        const unsigned m0 = (unsigned)jq[0] | ((unsigned)je[0] << 6) | ((bq[0] == hs[0]) ? (1u << 13) : 0u) | ((be[0] == hs[0]) ? (1u << 14) : 0u) | ((unsigned)opn0 << 15);
-                        const unsigned m1 = (unsigned)jq[1] | ((unsigned)je[1] << 6) | ((bq[1] == hs[1]) ? (1u << 13) : 0u) | ((be[1] == hs[1]) ? (1u << 14) : 0u) | ((unsigned)opn_next[0] << 15);
-                        const int si = s0 + i;
-                        rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be[0]; rec[si][F_ES1][lane] = be[1];
-                        rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1]; rec[si][F_META][lane] = (int)(m0 | (m1 << 16));
+                        bq0 = max(bq0, v.hl + sc0); bq1 = max(bq1, v.h0 + sc1);
+                        be0 = max(be0, max(v.e0 + E, v.h0 + OE));
+                        be1 = max(be1, max(v.e1 + E, v.h1 + OE));
                     }
                 }
-                // the counter follows the record: the LDS performs one wave's operations in issue order, so no wait is needed
-                // here (a workgroup-scope release fence would drain the seven writes first: ~150 cycles on the chain of rows);
-                // the wavefront-scope fence only keeps the compiler from reordering
+                int a[kDfKC], hs[kDfKC], fl[kDfKC], opn_next[kDfKC];
+                a[0] = max(bq0, be0); a[1] = max(bq1, be1);
+                df_scan_row(a, xin_row, cl, cl1, E, O, hs, fl, opn_next);
+                const int si = s0 + i;
+                rec[si][F_HS0][lane] = hs[0]; rec[si][F_HS1][lane] = hs[1]; rec[si][F_ES0][lane] = be0; rec[si][F_ES1][lane] = be1;
+                rec[si][F_FL0][lane] = fl[0]; rec[si][F_FL1][lane] = fl[1];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __hip_atomic_store(&produced[lane], rows_base + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be[0]; es_prev[1] = be[1];
+                hs_prev[0] = hs[0]; hs_prev[1] = hs[1]; es_prev[0] = be0; es_prev[1] = be1;
                 prev_r = r; edge_prev = my_edge;
                 ++i;
             }
-            if (__ballot(spread_l > 0)) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) spread_l = max(spread_l, __shfl_xor(spread_l, off, 64));
-                if (lane == 0) atomicMax(A.best + 8, spread_l);
-            }
         } else {
             // ================================================================ emitters: rows i = wave-1, wave+2, ...
-            // Written for instruction count (three emitters must keep up with a solver that spends ~55 instructions per
-            // backbone row): wave-uniform row index and row kind (scalar branches, scalar address arithmetic), the values of
-            // the lane on the left by DPP, branch-free selects for the codes.
+            // A row's record holds H, Eagg, F; which predecessor gave the diagonal / the vertical gap and whether that gap was an
+            // open (the reference's codes: c-t-simd.c:485-506, 521-538, 564-565) is worked out here from the records of the row's
+            // predecessors, off the chain of rows.  Written for instruction count (three emitters must keep up with a solver
+            // that spends ~55 instructions per backbone row): wave-uniform row index (scalar branches, scalar address
+            // arithmetic), the values of the lane on the left by DPP, branch-free selects for the codes.
             int slot_l = 0, base_l = 0;
             if (lane < nrows) { slot_l = A.slot[r0 + lane]; base_l = A.base[r0 + lane]; }
             __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0) here: or every row would wait for the stores of the row before
-            int edge_b = 0, flag_b = 0;
-            unsigned long long kmask = 0;
-            bool have_blk = false;
-            for (int i0 = wave - 1; i0 < nrows; i0 += 3) {
-                const int i = __builtin_amdgcn_readfirstlane(i0);
+            int spread_l = 0;
+            // the block's side data (the solver wrote them before the block's first record), one row per lane
+            const bool live = (wave - 1 >= nrows) || lds_wait_gt(&produced[lane], rows_base + wave - 1, P.status, lane);
+            const int sl_b = s0 + (lane & (kDfRB - 1));
+            const int edge_b = side[S_EDGE][sl_b], flag_b = side[S_FLAG][sl_b], np_b = side[S_NP][sl_b], poff_b = side[S_POFF][sl_b];
+            const int pr_b[4] = {side[S_PR0][sl_b], side[S_PR1][sl_b], side[S_PR2][sl_b], side[S_PR3][sl_b]};
+            const int ps_b[4] = {side[S_PS0][sl_b], side[S_PS1][sl_b], side[S_PS2][sl_b], side[S_PS3][sl_b]};
+            const unsigned long long near_mask = __ballot(lane < nrows && np_b >= 1 && np_b <= 4 && pr_b[0] >= ring_lo && (np_b < 2 || pr_b[1] >= ring_lo) &&
+                                                          (np_b < 3 || pr_b[2] >= ring_lo) && (np_b < 4 || pr_b[3] >= ring_lo));
+            for (int i = wave - 1; live && i < nrows; i += 3) {
                 if (!lds_wait_gt(&produced[lane], rows_base + i, P.status, lane)) break;
-                if (!have_blk) {
-                    // the block's side data (the solver wrote them before the block's first record), one row per lane
-                    const int l = s0 + (lane & (kDfRB - 1));
-                    edge_b = row_edge[l]; flag_b = row_flag[l];
-                    kmask = __ballot(row_kind[l] != 0 && lane < kDfRB);
-                    have_blk = true;
-                }
-                const int r = r0 + i, si = s0 + i, sp = max(si - 1, 0);
+                const int r = r0 + i, si = s0 + i;
                 const int hs0 = rec[si][F_HS0][lane], hs1 = rec[si][F_HS1][lane], es0 = rec[si][F_ES0][lane], es1 = rec[si][F_ES1][lane];
                 const int fl0 = rec[si][F_FL0][lane], fl1 = rec[si][F_FL1][lane];
-                const int ph0 = rec[sp][F_HS0][lane], ph1 = rec[sp][F_HS1][lane];          // the row above (used by backbone rows)
-                const unsigned metaw = (unsigned)rec[si][F_META][lane];                    // (used by the other rows)
                 const int myslot = __builtin_amdgcn_readlane(slot_l, i);
                 const int bs = __builtin_amdgcn_readlane(base_l, i);
+                const int np = __builtin_amdgcn_readlane(np_b, i);
                 const bool mt0 = (sch[0] == bs), mt1 = (sch[1] == bs);
-                const int hO0 = hs0 + O, hO1 = hs1 + O, hOE0 = hO0 + E, hOE1 = hO1 + E;
-                int code0, code1, ep0, ep1, opn0, opn1;
-                if ((kmask >> i) & 1ull) {
-                    // backbone row: its single predecessor is row i-1 of this block; what the solver did not write is rebuilt
-                    // from that row's record (c-t-simd.c:485-506, 524-538, 564-565)
-                    const int edge_p = __builtin_amdgcn_readlane(edge_b, i - 1), flag_r = __builtin_amdgcn_readlane(flag_b, i);
-                    const int phl = df_shr1(edge_p, ph1);                                  // H(p, column left of this lane)
-                    const int bq0 = phl + (mt0 ? M : X), bq1 = ph0 + (mt1 ? M : X);
-                    // F-open flag of a column: H(c-1) + O >= F(c-1); the lane's first column looks at the lane on the left / the chunk edge
-                    opn1 = (hO0 >= fl0) ? 1 : 0;
-                    opn0 = df_shr1(flag_r, (hO1 >= fl1) ? 1 : 0);
-                    code0 = (bq0 == hs0) ? (mt0 ? 42 : 84) : ((es0 == hs0) ? 0 : 126);   // match > mismatch > E > F (c-t-simd.c:485-506)
-                    code1 = (bq1 == hs1) ? (mt1 ? 42 : 84) : ((es1 == hs1) ? 0 : 126);
-                    ep0 = (es0 == ph0 + OE) ? 43 : 1;                                      // c-t-simd.c:530-538
-                    ep1 = (es1 == ph1 + OE) ? 43 : 1;
+                const int sc0 = mt0 ? M : X, sc1 = mt1 ? M : X;
+                int bq0 = kNeg, bq1 = kNeg, be0 = kNeg, be1 = kNeg, jq0 = 0, jq1 = 0, je0 = 0, je1 = 0;
+                int hmx0 = kNeg, hmx1 = kNeg, hmn0 = -kNeg, hmn1 = -kNeg;
+                // one predecessor's share: lowest predecessor index wins ties (strict >), je bit 6 = "the vertical gap opened"
+                auto take = [&](int j, int hl, int h0, int h1, int e0, int e1) {
+                    const int qv0 = hl + sc0, qv1 = h0 + sc1;                                  // diagonal from H(p, c-1)
+                    if (qv0 > bq0) { bq0 = qv0; jq0 = j; }
+                    if (qv1 > bq1) { bq1 = qv1; jq1 = j; }
+                    const int eo0 = h0 + OE, eo1 = h1 + OE;                                     // c-t-simd.c:524-528
+                    const int ei0 = max(e0 + E, eo0), ei1 = max(e1 + E, eo1);
+                    if (ei0 > be0) { be0 = ei0; je0 = j | ((ei0 == eo0) ? 64 : 0); }
+                    if (ei1 > be1) { be1 = ei1; je1 = j | ((ei1 == eo1) ? 64 : 0); }
+                    hmx0 = max(hmx0, h0); hmn0 = min(hmn0, h0); hmx1 = max(hmx1, h1); hmn1 = min(hmn1, h1);
+                };
+                if ((near_mask >> i) & 1ull) {
+                    // every predecessor's record is in the ring: the reads of the first two go out together
+                    PredVals va, vb;
+                    int eda, edb = 0;
+                    { const int sl = ring_slot(__builtin_amdgcn_readlane(pr_b[0], i));
+                      va.h0 = rec[sl][F_HS0][lane]; va.h1 = rec[sl][F_HS1][lane]; va.e0 = rec[sl][F_ES0][lane]; va.e1 = rec[sl][F_ES1][lane]; eda = side[S_EDGE][sl]; }
+                    if (np > 1) {
+                        const int sl = ring_slot(__builtin_amdgcn_readlane(pr_b[1], i));
+                        vb.h0 = rec[sl][F_HS0][lane]; vb.h1 = rec[sl][F_HS1][lane]; vb.e0 = rec[sl][F_ES0][lane]; vb.e1 = rec[sl][F_ES1][lane]; edb = side[S_EDGE][sl];
+                    }
+                    {   // predecessor 0 (no comparison needed)
+                        const int eo0 = va.h0 + OE, eo1 = va.h1 + OE;
+                        bq0 = df_shr1(eda, va.h1) + sc0; bq1 = va.h0 + sc1;
+                        be0 = max(va.e0 + E, eo0); be1 = max(va.e1 + E, eo1);
+                        je0 = (be0 == eo0) ? 64 : 0; je1 = (be1 == eo1) ? 64 : 0;
+                        hmx0 = hmn0 = va.h0; hmx1 = hmn1 = va.h1;
+                    }
+                    if (np > 1) {
+                        take(1, df_shr1(edb, vb.h1), vb.h0, vb.h1, vb.e0, vb.e1);
+                        for (int j = 2; j < np; ++j) {
+                            const int sl = ring_slot(j == 2 ? __builtin_amdgcn_readlane(pr_b[2], i) : __builtin_amdgcn_readlane(pr_b[3], i));
+                            const int h0 = rec[sl][F_HS0][lane], h1 = rec[sl][F_HS1][lane], e0 = rec[sl][F_ES0][lane], e1 = rec[sl][F_ES1][lane];
+                            take(j, df_shr1(side[S_EDGE][sl], h1), h0, h1, e0, e1);
+                        }
+                    }
                 } else {
-                    const int m0 = (int)(metaw & 0xffffu), m1 = (int)(metaw >> 16);
-                    const int je0 = (m0 >> 6) & 127, je1 = (m1 >> 6) & 127;
-                    code0 = (m0 & (1 << 13)) ? (mt0 ? 42 : 84) + (m0 & 63) : ((m0 & (1 << 14)) ? (je0 & 63) : 126);
-                    code1 = (m1 & (1 << 13)) ? (mt1 ? 42 : 84) + (m1 & 63) : ((m1 & (1 << 14)) ? (je1 & 63) : 126);
-                    ep0 = ((je0 & 64) ? 43 : 1) + (je0 & 63);
-                    ep1 = ((je1 & 64) ? 43 : 1) + (je1 & 63);
-                    opn0 = (m0 >> 15) & 1; opn1 = (m1 >> 15) & 1;
+                    const bool is_src = (np == 0);
+                    const int p0 = __builtin_amdgcn_readlane(poff_b, i);
+                    const int npp = is_src ? 1 : np;
+                    for (int j = 0; j < npp; ++j) {
+                        int p = A.V, ps = 0;
+                        if (!is_src) {
+                            if (j == 0) { p = __builtin_amdgcn_readlane(pr_b[0], i); ps = __builtin_amdgcn_readlane(ps_b[0], i); }
+                            else if (j == 1) { p = __builtin_amdgcn_readlane(pr_b[1], i); ps = __builtin_amdgcn_readlane(ps_b[1], i); }
+                            else if (j == 2) { p = __builtin_amdgcn_readlane(pr_b[2], i); ps = __builtin_amdgcn_readlane(ps_b[2], i); }
+                            else if (j == 3) { p = __builtin_amdgcn_readlane(pr_b[3], i); ps = __builtin_amdgcn_readlane(ps_b[3], i); }
+                            else { p = __builtin_amdgcn_readfirstlane(A.pred[p0 + j]); ps = __builtin_amdgcn_readfirstlane(A.pred_slot[p0 + j]); }
+                        }
+                        PredVals v;
+                        if (!is_src && p >= ring_lo) {
+                            const int sl = ring_slot(p);
+                            v.h0 = rec[sl][F_HS0][lane]; v.h1 = rec[sl][F_HS1][lane]; v.e0 = rec[sl][F_ES0][lane]; v.e1 = rec[sl][F_ES1][lane];
+                            v.hl = df_shr1(side[S_EDGE][sl], v.h1);
+                        } else {
+                            v = pred_far(p, ps, is_src);
+                        }
+                        take(j, v.hl, v.h0, v.h1, v.e0, v.e1);
+                    }
                 }
+                if (np > 1) {                                 // largest distance between two predecessor rows of a node (tsta_engine.h: warnings)
+                    if (c0 < n) spread_l = max(spread_l, hmx0 - hmn0);
+                    if (c0 + 1 < n) spread_l = max(spread_l, hmx1 - hmn1);
+                }
+                const int hO0 = hs0 + O, hO1 = hs1 + O, hOE0 = hO0 + E, hOE1 = hO1 + E;
+                // F-open flag of a column: H(c-1) + O >= F(c-1); the lane's first column looks at the lane on the left / the chunk edge
+                const int opn1 = (hO0 >= fl0) ? 1 : 0;
+                const int opn0 = df_shr1(__builtin_amdgcn_readlane(flag_b, i), (hO1 >= fl1) ? 1 : 0);
+                // match > mismatch > E > F (c-t-simd.c:485-506)
+                const int code0 = (bq0 == hs0) ? (mt0 ? 42 : 84) + jq0 : ((es0 == hs0) ? (je0 & 63) : 126);
+                const int code1 = (bq1 == hs1) ? (mt1 ? 42 : 84) + jq1 : ((es1 == hs1) ? (je1 & 63) : 126);
+                const int ep0 = ((je0 & 64) ? 43 : 1) + (je0 & 63), ep1 = ((je1 & 64) ? 43 : 1) + (je1 & 63);       // c-t-simd.c:530-538
                 const int ec0 = (es0 + E == hOE0) ? -ep0 : ep0, ec1 = (es1 + E == hOE1) ? -ep1 : ep1;
                 const int fp0 = opn0 + 1, fp1 = opn1 + 1;                                   // c-t-simd.c:521-522,564-565
                 const int fc0 = (fl0 + E == hOE0) ? -fp0 : fp0, fc1 = (fl1 + E == hOE1) ? -fp1 : fp1;
@@ -467,10 +499,15 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                     store_sc1_int2(reinterpret_cast<int2*>(hd + 2), hs1, 0);                            // H at the chunk's right edge
                 }
             }
+            if (__ballot(spread_l > 0)) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) spread_l = max(spread_l, __shfl_xor(spread_l, off, 64));
+                if (lane == 0) atomicMax(A.best + 8, spread_l);
+            }
         }
         // No barrier: the solver runs on into the next block while the emitters finish this one.  Every wave, once ITS stores
-        // of the block have left, counts itself in; the fourth one publishes the block — to the chunk on the right (prog[q],
-        // sc1) and to this workgroup's solver (blk_pub: it may then recycle the block's ring half two blocks later).
+        // of the block have left, counts itself in; the fourth one publishes the block — to the chunk on the right (prog[q+1],
+        // sc1) and to this workgroup's solver (blk_pub: it may then recycle the block's ring third two blocks later).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const int before = __hip_atomic_fetch_add(&blk_done[rb & 3], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
