@@ -1,21 +1,25 @@
-// poa_dataflow.hip — K4d: the POA fill of poa_fill.hip as ONE launch, with the per-row work of a tile split over the four
-// waves of a workgroup.  Same results (reference: msa/c-t-simd.c:165-599, 602-657, 979-1045; see poa_fill.hip).
+// poa_dataflow.hip — K4d: the POA fill of poa_fill.hip as ONE launch, with the work of a row split over the waves of a
+// workgroup.  Same results (reference: msa/c-t-simd.c:165-599, 602-657, 979-1045; see poa_fill.hip).
 //
 // Why.  The README example is a latency problem: 5 000 columns are only 40 tiles wide, so a fill is as long as
-// the chain of its rows, V x (time per row), and K4 spends ~0.9 us per row: one wave does everything a row needs (~460
-// instructions at the single-wave issue rate) and every tile anti-diagonal is a kernel launch.  Two things change here:
+// the chain of its rows, V x (time per row), and a lone wave issues one instruction every ~8 cycles: the time per row IS the
+// number of instructions on the wave that owns the chain.  K4 spends ~460 instructions per row and a launch per tile
+// anti-diagonal.  Here:
 //
-//  1. One workgroup per chunk of 128 columns instead of one launch per tile anti-diagonal.  Workgroup q sweeps ALL the
-//     nodes of its chunk, 32 at a time; before each block of 32 it waits until the workgroup on its left has published that
-//     block (prog[q-1] > block), then publishes its own.  A workgroup waits only for its left neighbour and all of them are
-//     resident (<= 128 chunks), so the waits always end.  What crosses chunks goes through sc1 stores / loads (handoff.h):
-//     per row the F carry, the open flag and H at the chunk's right edge.  The chain of rows — the critical path — never
-//     leaves the workgroup: the backbone predecessor stays in the solver's registers from one block to the next, other
-//     predecessors come from the block's LDS records or (earlier blocks) from the H / Eagg rows this same workgroup stored.
-//  2. Solver + emitters.  Wave 0 of the workgroup (the solver) runs only what the NEXT row needs: predecessor maxima, the
-//     max-plus scan of F, final H / Eagg / F.  It leaves 7 dwords per lane and row in an LDS record; waves 1-3 (emitters, rows
-//     i = e mod 3) turn records into the reference's three trace codes (c-t-simd.c:485-506, 521-538, 564-565) and do all the
-//     stores.  The solver's chain is ~100 instructions per row instead of ~460.
+//  1. One workgroup per chunk of 128 columns, one launch.  Workgroup q sweeps ALL the nodes of its chunk, 32 at a time (a
+//     "block"); it takes over, per row, three values from the chunk on its left (F carry, open flag, H at the edge: `hand`,
+//     sc1 stores / loads, handoff.h) once that chunk has published the block (prog[q]), and publishes its own.  A workgroup
+//     waits only for its left neighbour and all of them are resident, so the waits always end.  Column 0 — H(r, 0), a function
+//     of the graph alone — is one more workgroup (a single wave) that plays "left neighbour" for chunk 0.
+//  2. Roles.  Wave 0, the SOLVER, runs only what the next row needs — predecessor maxima, the max-plus scan of F, final
+//     H / Eagg / F — and leaves six dwords per lane and row in an LDS ring of three blocks: ~55 instructions per backbone row
+//     (one predecessor = the row before, tight loop), ~100 for a row with several / non-adjacent predecessors whose records
+//     are in the ring.  Four EMITTER waves (rows i mod 4) work out again, from the records of a row's predecessors, everything
+//     the reference's three trace codes record (c-t-simd.c:485-506, 521-538, 564-565) and do all the stores.  The FETCHER wave
+//     reads what a block needs from global memory — DAG metadata, the left neighbour's hand-over — up to two blocks ahead into
+//     LDS, polling the neighbour's flag: no global-memory latency sits on the chain of rows.
+//  3. Nobody waits at a barrier: records are followed by a counter (the LDS performs one wave's operations in order), a block
+//     is published by whichever wave finishes it last.
 //
 // Scope: 2 columns per lane (sequences up to 16 384) and sequences without a literal 'N' (the N-column rule needs the
 // segment-by-segment scan of poa_fill.hip); everything else runs the launch-per-diagonal K4.
@@ -34,7 +38,8 @@ namespace tsta {
 constexpr int kDfKC = 2;                 // columns per lane
 constexpr int kDfCW = 64 * kDfKC;        // columns per chunk
 constexpr int kDfRB = 32;                // nodes per block
-constexpr int kDfThreads = 320;           // solver, three emitters, fetcher
+constexpr int kDfThreads = 384;          // solver (wave 0), emitters (waves 1-3 and 5), fetcher (wave 4)
+constexpr int kDfEmit = 4;               // emitter waves
 constexpr int kDfRing = 3 * kDfRB;       // rows whose records stay in LDS: three blocks (the solver writes one and reads the one before it,
                                          // the emitters of that one still read the third): 96 x 6 x 64 ints = 144 KB
 
@@ -60,6 +65,22 @@ __device__ __forceinline__ bool lds_wait_gt(int* word, int v, unsigned* status, 
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }      // ~1 s: far beyond any ramp-up of the chunks
         // once any wave of the launch has given up, nobody waits any more
+        if ((spins & 4095) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+
+// the same for a counter that only grows: `seen` keeps the last value read, so a reader that is behind does not look again
+__device__ __forceinline__ bool lds_wait_gt_seen(int* word, int v, int& seen, unsigned* status, int lane)
+{
+    if (seen > v) return true;
+    int spins = 0;
+    for (;;) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (seen > v) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 24)) { if (lane == 0) atomicOr(status, 2u); return false; }
         if ((spins & 4095) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -132,33 +153,58 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
         // ahead of chunk 0 and hands it, per row, what every other chunk gets from the chunk on its left: the F carry
         // (F(r, 0) = -inf, so the carry is H + O and the first F opens), and H at the "edge".  Chunk 0 is then a chunk like
         // any other.
+        // Nothing global sits on its per-block path either: the predecessor lists are loaded one block ahead (their offsets two),
+        // the previous block's values stay in a register (older ones are read back), a block is published once its stores
+        // have had the next block's time to drain.
         if (wave != 0) return;
         const int nblk = (A.V + kDfRB - 1) / kDfRB;
+        struct Lists { int poff, np, pr[4]; };
+        auto load_offsets = [&](int rb, int& poff, int& np) {
+            const int r0 = rb * kDfRB, nrows = min(A.V, r0 + kDfRB) - r0;
+            poff = 0; np = 0;
+            if (rb < nblk && lane < nrows) { poff = A.pred_off[r0 + lane]; np = A.pred_off[r0 + lane + 1] - poff; }
+        };
+        auto load_lists = [&](int poff, int np) -> Lists {
+            Lists L; L.poff = poff; L.np = np;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) L.pr[x] = (x < np) ? A.pred[poff + x] : -1;
+            return L;
+        };
+        int poff_n, np_n;
+        load_offsets(0, poff_n, np_n);
+        Lists cur = load_lists(poff_n, np_n);            // block 0
+        load_offsets(1, poff_n, np_n);                   // block 1's offsets
+        int h_prev = 0;                                  // lane i: H(r0 - 32 + i, 0), the previous block
         for (int rb = 0; rb < nblk; ++rb) {
             const int r0 = rb * kDfRB, nrows = min(A.V, r0 + kDfRB) - r0;
-            int poff = 0, np = 0, pr[4] = {-1, -1, -1, -1};
-            int ext = kNeg;                              // max H(p, 0) over the predecessors before this block, one row per lane
-            if (lane < nrows) {
-                poff = A.pred_off[r0 + lane]; np = A.pred_off[r0 + lane + 1] - poff;
-                for (int j = 0; j < np; ++j) {
-                    const int p = A.pred[poff + j];
-                    if (j < 4) pr[j] = p;
-                    if (p < r0) ext = max(ext, load_sc1_int(&P.hand[((size_t)p * ncar) * 4 + 2]));
-                }
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): everything issued a block ago (lists, offsets, stores) has landed
+            if (rb > 0) { if (lane == 0) __hip_atomic_store((GlobalI32*)P.prog, rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // block rb-1
+            const Lists L = cur;
+            cur = load_lists(poff_n, np_n);              // block rb+1 (offsets loaded a block ago)
+            load_offsets(rb + 2, poff_n, np_n);
+            // max H(p, 0) over the predecessors before this block, one row per lane
+            int ext = kNeg;
+            for (int j = 0; __ballot(lane < nrows && j < L.np) != 0ull; ++j) {       // (uniform loop: the shuffle needs every lane)
+                const bool mine = lane < nrows && j < L.np;
+                int p = (j == 0) ? L.pr[0] : (j == 1) ? L.pr[1] : (j == 2) ? L.pr[2] : (j == 3) ? L.pr[3] : -1;
+                if (mine && j >= 4) p = A.pred[L.poff + j];
+                int hv = __shfl(h_prev, (p - (r0 - kDfRB)) & 63, 64);
+                if (mine && p < r0 - kDfRB) hv = load_sc1_int(&P.hand[((size_t)p * ncar) * 4 + 2]);
+                if (mine && p < r0) ext = max(ext, hv);
             }
             int h_l = 0;                                 // lane i: H(r0 + i, 0)
             for (int i = 0; i < nrows; ++i) {
-                const int npi = __builtin_amdgcn_readlane(np, i);
+                const int npi = __builtin_amdgcn_readlane(L.np, i);
                 int h = OE;
                 if (npi > 0) {
                     h = __builtin_amdgcn_readlane(ext, i);
-                    const int p0 = __builtin_amdgcn_readlane(poff, i);
+                    const int p0 = __builtin_amdgcn_readlane(L.poff, i);
                     for (int j = 0; j < npi; ++j) {
                         int p;
-                        if (j == 0) p = __builtin_amdgcn_readlane(pr[0], i);
-                        else if (j == 1) p = __builtin_amdgcn_readlane(pr[1], i);
-                        else if (j == 2) p = __builtin_amdgcn_readlane(pr[2], i);
-                        else if (j == 3) p = __builtin_amdgcn_readlane(pr[3], i);
+                        if (j == 0) p = __builtin_amdgcn_readlane(L.pr[0], i);
+                        else if (j == 1) p = __builtin_amdgcn_readlane(L.pr[1], i);
+                        else if (j == 2) p = __builtin_amdgcn_readlane(L.pr[2], i);
+                        else if (j == 3) p = __builtin_amdgcn_readlane(L.pr[3], i);
                         else p = __builtin_amdgcn_readfirstlane(A.pred[p0 + j]);
                         if (p >= r0) h = max(h, __builtin_amdgcn_readlane(h_l, p - r0));
                     }
@@ -171,8 +217,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 store_sc1_int2(reinterpret_cast<int2*>(hd), h_l + O, 1);
                 store_sc1_int2(reinterpret_cast<int2*>(hd + 2), h_l, 0);
             }
-            publish_progress(P.prog, rb + 1, lane);
+            h_prev = h_l;
         }
+        publish_progress(P.prog, nblk, lane);
         return;
     }
     const int cbase = q * kDfCW, c0 = cbase + lane * kDfKC;
@@ -189,15 +236,32 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
         // chunk on the left handed over — is read by this wave up to two blocks ahead and left in LDS: no global-memory
         // latency (and no wait for a neighbour's flag) sits on the chain of rows.  The flag of the chunk on the left is
         // polled here (prog[q]; prog[0] belongs to column 0).
+        // Software-pipelined like column 0: a block's predecessor lists are loaded while the block before it is handed over,
+        // their offsets one block earlier still; per block only the neighbour's flag and its hand-over are waited for.
+        struct FMeta { int poff, np, base, pr[4], ps[4]; };
+        auto load_offsets = [&](int rb, int& poff, int& np, int& base) {
+            const int r0 = rb * kDfRB, count = min(A.V, r0 + kDfRB) - r0;
+            poff = 0; np = 0; base = 0;
+            if (rb < nblocks && lane < count) { poff = A.pred_off[r0 + lane]; np = A.pred_off[r0 + lane + 1] - poff; base = A.base[r0 + lane]; }
+        };
+        auto load_lists = [&](int poff, int np, int base) -> FMeta {
+            FMeta m; m.poff = poff; m.np = np; m.base = base;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { m.pr[x] = -1; m.ps[x] = 0; if (x < np) { m.pr[x] = A.pred[poff + x]; m.ps[x] = A.pred_slot[poff + x]; } }
+            return m;
+        };
+        int poff_n, np_n, base_n;
+        load_offsets(0, poff_n, np_n, base_n);
+        FMeta nxt = load_lists(poff_n, np_n, base_n);    // block 0
+        load_offsets(1, poff_n, np_n, base_n);
         for (int rb = 0; rb < nblocks; ++rb) {
             const int r0 = rb * kDfRB, count = min(A.V, r0 + kDfRB) - r0;
-            int poff = 0, np = 0, base = 0, pr[4] = {-1, -1, -1, -1}, ps[4] = {0, 0, 0, 0};
-            if (lane < count) {
-                poff = A.pred_off[r0 + lane]; base = A.base[r0 + lane];
-                np = A.pred_off[r0 + lane + 1] - poff;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (x < np) { pr[x] = A.pred[poff + x]; ps[x] = A.pred_slot[poff + x]; }
-            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): issued an iteration ago
+            const FMeta m = nxt;
+            nxt = load_lists(poff_n, np_n, base_n);      // block rb+1
+            load_offsets(rb + 2, poff_n, np_n, base_n);
+            const int poff = m.poff, np = m.np, base = m.base;
+            const int (&pr)[4] = m.pr; const int (&ps)[4] = m.ps;
             if (rb >= 2 && !lds_wait_gt(&taken, rb - 2, P.status, lane)) break;     // the solver has copied block rb-2 out of this slot
             wait_progress(P.prog + q, rb + 1, P.status, lane);
             int xin = 0, flag = 1, edge = 0;
@@ -216,7 +280,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the LDS performs one wave's operations in order
             if (lane == 0) __hip_atomic_store(&fetched, rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return;
+            return;
     }
     // One predecessor row as a lane sees it: H at the column left of the lane's first column, H and Eagg at its two columns.
     struct PredVals { int hl, h0, h1, e0, e1; };
@@ -382,15 +446,17 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0) here: or every row would wait for the stores of the row before
             int spread_l = 0;
             // the block's side data (the solver wrote them before the block's first record), one row per lane
-            const bool live = (wave - 1 >= nrows) || lds_wait_gt(&produced[lane], rows_base + wave - 1, P.status, lane);
+            const int em = (wave == 5) ? 3 : wave - 1;        // emitter number: rows em, em + 4, ...
+            int seen = 0;
+            const bool live = (em >= nrows) || lds_wait_gt_seen(&produced[lane], rows_base + em, seen, P.status, lane);
             const int sl_b = s0 + (lane & (kDfRB - 1));
             const int edge_b = side[S_EDGE][sl_b], flag_b = side[S_FLAG][sl_b], np_b = side[S_NP][sl_b], poff_b = side[S_POFF][sl_b];
             const int pr_b[4] = {side[S_PR0][sl_b], side[S_PR1][sl_b], side[S_PR2][sl_b], side[S_PR3][sl_b]};
             const int ps_b[4] = {side[S_PS0][sl_b], side[S_PS1][sl_b], side[S_PS2][sl_b], side[S_PS3][sl_b]};
             const unsigned long long near_mask = __ballot(lane < nrows && np_b >= 1 && np_b <= 4 && pr_b[0] >= ring_lo && (np_b < 2 || pr_b[1] >= ring_lo) &&
                                                           (np_b < 3 || pr_b[2] >= ring_lo) && (np_b < 4 || pr_b[3] >= ring_lo));
-            for (int i = wave - 1; live && i < nrows; i += 3) {
-                if (!lds_wait_gt(&produced[lane], rows_base + i, P.status, lane)) break;
+            for (int i = em; live && i < nrows; i += kDfEmit) {
+                if (!lds_wait_gt_seen(&produced[lane], rows_base + i, seen, P.status, lane)) break;
                 const int r = r0 + i, si = s0 + i;
                 const int hs0 = rec[si][F_HS0][lane], hs1 = rec[si][F_HS1][lane], es0 = rec[si][F_ES0][lane], es1 = rec[si][F_ES1][lane];
                 const int fl0 = rec[si][F_FL0][lane], fl1 = rec[si][F_FL1][lane];
@@ -470,8 +536,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 const int opn1 = (hO0 >= fl0) ? 1 : 0;
                 const int opn0 = df_shr1(__builtin_amdgcn_readlane(flag_b, i), (hO1 >= fl1) ? 1 : 0);
                 // match > mismatch > E > F (c-t-simd.c:485-506)
-                const int code0 = (bq0 == hs0) ? (mt0 ? 42 : 84) + jq0 : ((es0 == hs0) ? (je0 & 63) : 126);
-                const int code1 = (bq1 == hs1) ? (mt1 ? 42 : 84) + jq1 : ((es1 == hs1) ? (je1 & 63) : 126);
+                const int cd0 = (mt0 ? 42 : 84) + jq0, cd1 = (mt1 ? 42 : 84) + jq1;           // the three candidates first: selects, no branches
+                const int ce0 = (es0 == hs0) ? (je0 & 63) : 126, ce1 = (es1 == hs1) ? (je1 & 63) : 126;
+                const int code0 = (bq0 == hs0) ? cd0 : ce0, code1 = (bq1 == hs1) ? cd1 : ce1;
                 const int ep0 = ((je0 & 64) ? 43 : 1) + (je0 & 63), ep1 = ((je1 & 64) ? 43 : 1) + (je1 & 63);       // c-t-simd.c:530-538
                 const int ec0 = (es0 + E == hOE0) ? -ep0 : ep0, ec1 = (es1 + E == hOE1) ? -ep1 : ep1;
                 const int fp0 = opn0 + 1, fp1 = opn1 + 1;                                   // c-t-simd.c:521-522,564-565
@@ -479,16 +546,17 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 const unsigned w1 = (unsigned)(code0 & 0xff) | ((unsigned)(code1 & 0xff) << 8);
                 const unsigned w2 = (unsigned)(ec0 & 0xff) | ((unsigned)(ec1 & 0xff) << 8);
                 const unsigned w3 = (unsigned)(fc0 & 0xff) | ((unsigned)(fc1 & 0xff) << 8);
+                // (row bases are wave-uniform: scalar address arithmetic, the lane only adds its index)
                 int* Hr = A.Hrow + (size_t)myslot * A.pitch;
                 int* Er = A.Erow + (size_t)myslot * A.pitch;
                 if (c0 < n) {
-                    store_sc1_int2(reinterpret_cast<int2*>(Hr + c0 + 4), hs0, hs1);              // H(r, c0+1..c0+2): read by later blocks of this launch
-                    store_sc1_int2(reinterpret_cast<int2*>(Er + c0), es0, es1);
+                    store_sc1_int2(reinterpret_cast<int2*>(Hr + cbase + 4) + lane, hs0, hs1);     // H(r, c0+1..c0+2): read by later blocks of this launch
+                    store_sc1_int2(reinterpret_cast<int2*>(Er + cbase) + lane, es0, es1);
                     if (A.source) {                                                           // trace: read after the launch only
-                        const size_t toff = (size_t)r * A.tpitch;
-                        *reinterpret_cast<unsigned short*>(A.source + toff + c0) = (unsigned short)w1;
-                        *reinterpret_cast<unsigned short*>(A.esource + toff + c0) = (unsigned short)w2;
-                        *reinterpret_cast<unsigned short*>(A.fsource + toff + c0) = (unsigned short)w3;
+                        const size_t toff = (size_t)r * A.tpitch + cbase;
+                        reinterpret_cast<unsigned short*>(A.source + toff)[lane] = (unsigned short)w1;
+                        reinterpret_cast<unsigned short*>(A.esource + toff)[lane] = (unsigned short)w2;
+                        reinterpret_cast<unsigned short*>(A.fsource + toff)[lane] = (unsigned short)w3;
                     }
                 }
                 if (q == A.nchunks - 1 && c0 < n && c0 + kDfKC >= n) A.lastscore[r] = (n - 1 - c0 == 1) ? hs1 : hs0;   // owner of the last column
@@ -511,7 +579,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const int before = __hip_atomic_fetch_add(&blk_done[rb & 3], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (before == 3) {
+            if (before == kDfEmit) {
                 __hip_atomic_store(&blk_done[rb & 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store((GlobalI32*)(P.prog + q + 1), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&blk_pub, rb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
