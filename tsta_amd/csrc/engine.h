@@ -46,6 +46,8 @@ struct Engine {
 
     void set_error(const char* fmt, ...);
     int  check(hipError_t e, const char* what);
+    // small blocking copies ON THE ENGINE'S STREAM (a plain hipMemcpy would bring up the process's null stream: ~15 ms the first time)
+    int  copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
     int  reserve(DevBuf& b, size_t bytes, const char* what, bool growing = false);
     void timing_begin(hipStream_t s);
     void timing_end(hipStream_t s);

@@ -22,6 +22,12 @@ void Engine::set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+int Engine::copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what)
+{
+    int rc = check(hipMemcpyAsync(dst, src, bytes, kind, stream), what);
+    return rc ? rc : check(hipStreamSynchronize(stream), what);
+}
+
 int Engine::check(hipError_t e, const char* what)
 {
     if (e == hipSuccess) return TSTA_OK;

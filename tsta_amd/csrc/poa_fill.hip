@@ -453,12 +453,10 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     }
     int num1 = __builtin_amdgcn_readfirstlane(bi >= 0 ? bi : A.V - 1);
     int num2 = A.n - 1, forced = -1, ns = 0;
-    int st_win = 0, st_runs = 0, st_runcells = 0, st_serial = 0;
     if (lane == 0) A.out[2] = num1;
 
     while (num1 != -1 && num2 != -1) {
         // stage the window whose lower-right region holds (num1, num2)
-        ++st_win;
         const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
         {
             const int rr = rw0 + lane;
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                         tsta_poa_step st; st.node = r; st.col = c; st.code = (int8_t)code_l; st.peek = (int8_t)pk; st.pad = 0;
                         A.steps[ns + lane] = st;
                     }
-                    ns += run; num1 -= run; num2 -= run; ++st_runs; st_runcells += run;
+                    ns += run; num1 -= run; num2 -= run;
                     continue;
                 }
                 if (__builtin_amdgcn_readfirstlane(have ? 1 : 0)) probed_code = __builtin_amdgcn_readfirstlane(code_l);   // lane 0 probed (num1, num2) itself
@@ -571,12 +569,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 tsta_poa_step st; st.node = num1; st.col = num2; st.code = (int8_t)code; st.peek = (int8_t)peek; st.pad = 0;
                 A.steps[ns] = st;
             }
-            ++ns; ++st_serial;
+            ++ns;
             num1 = n1; num2 = n2;
         }
         __syncthreads();
     }
-    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; A.out[8] = st_win; A.out[9] = st_runs; A.out[10] = st_runcells; A.out[11] = st_serial; }
+    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; }
 }
 
 }  // namespace tsta
@@ -614,7 +612,7 @@ static int poa_dataflow_status(Engine* e)
 {
     if (!e->poa_status) return TSTA_OK;
     unsigned st = 0;
-    int rc = e->check(hipMemcpy(&st, e->poa_status, sizeof(st), hipMemcpyDeviceToHost), "D2H poa status");
+    int rc = e->copy_sync(&st, e->poa_status, sizeof(st), hipMemcpyDeviceToHost, "D2H poa status");
     if (rc != TSTA_OK) return rc;
     if (st) { e->set_error("POA dataflow fill: a tile waited too long for its producers (status %u)", st); return TSTA_ERR_INTERNAL; }
     return TSTA_OK;
@@ -803,18 +801,17 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
-    int h_out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
+    int h_out[5] = {0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
     if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
         return rc;
     if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     const int ns = h_out[0];
-    if (getenv("TSTA_WALK_STATS")) fprintf(stderr, "[walk] V=%d n=%d steps=%d windows=%d runs=%d runcells=%d serial=%d\n", V, n, ns, h_out[8], h_out[9], h_out[10], h_out[11]);
     if (ns < 0 || (size_t)ns > cap) { e->set_error("walker returned %d steps", ns); return TSTA_ERR_INTERNAL; }
     tsta_poa_step* out = (tsta_poa_step*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(tsta_poa_step));
     if (!out) return TSTA_ERR_OOM;
-    if (ns && (rc = e->check(hipMemcpy(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost), "D2H steps"))) { free(out); return rc; }
+    if (ns && (rc = e->copy_sync(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost, "D2H steps"))) { free(out); return rc; }
     *steps = out; *n_steps = ns; *end_col = h_out[1];
     return poa_reference_warning(e, p, V, seq, n, h_out[4]);
 }

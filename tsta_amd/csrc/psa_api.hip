@@ -328,7 +328,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
             hipStreamSynchronize(s) == hipSuccess && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, R, (long long)blocks);
-        if (couples && e->scratch2.p && hipMemcpy(h, e->scratch2.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[3] > h[1])
+        if (couples && e->scratch2.p && e->copy_sync(h, e->scratch2.p, sizeof(h), hipMemcpyDeviceToHost, "D2H clock") == TSTA_OK && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score_packed wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks, %d blocks/CU by API)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, Rp, (long long)pblocks,
                     tsta::psa_packed_blocks_per_cu(Rp));
@@ -392,7 +392,7 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
                 const uint8_t* b = seqs + (swap ? off1[k] : off2[k]); const int m = swap ? len1[k] : len2[k];
                 if ((rc = tsta::psa_score_single_pair(e, p, a, n, b, m, &res[k])) != TSTA_OK) return rc;
             }
-            if (d_scores) return e->check(hipMemcpy(*d_scores, res, nb * sizeof(int32_t), hipMemcpyHostToDevice), "H2D scores");
+            if (d_scores) return e->copy_sync(*d_scores, res, nb * sizeof(int32_t), hipMemcpyHostToDevice, "H2D scores");
             return TSTA_OK;
         }
     }

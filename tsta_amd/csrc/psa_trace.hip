@@ -846,7 +846,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         return rc;
     if (persistent || persistent_couples) {
         unsigned st = 0;
-        if ((rc = e->check(hipMemcpy(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost), "D2H status"))) return rc;
+        if ((rc = e->copy_sync(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost, "D2H status"))) return rc;
         if (st) { e->set_error("persistent trace fill: a band waited too long for the band above (status %u)", st); return TSTA_ERR_INTERNAL; }
     }
     // the walkers' ops: per-job copies for a few long alignments, one copy of the whole region for many short ones
