@@ -129,6 +129,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
+    if (const char* v = getenv("TSTA_POA_DATAFLOW")) e->opt_poa_dataflow = atoi(v) != 0;
     int rc;
     hipDeviceProp_t prop;
     if ((rc = e->check(hipSetDevice(device), "hipSetDevice")) != TSTA_OK ||

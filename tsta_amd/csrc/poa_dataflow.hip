@@ -21,7 +21,7 @@
 //  3. Nobody waits at a barrier: records are followed by a counter (the LDS performs one wave's operations in order), a block
 //     is published by whichever wave finishes it last.
 //
-// Scope: 2 columns per lane (sequences up to 16 384) and sequences without a literal 'N' (the N-column rule needs the
+// Scope: 2 columns per lane, one chunk per CU (sequences up to 255 x 128 = 32 640 columns) and sequences without a literal 'N' (the N-column rule needs the
 // segment-by-segment scan of poa_fill.hip); everything else runs the launch-per-diagonal K4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
