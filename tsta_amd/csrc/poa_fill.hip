@@ -425,22 +425,28 @@ __global__ void poa_best_kernel(PoaArgs A)
 
 // ---------------------------------------------------------------------------------------------- K4w
 // The traceback walk of node_fuse (c-t-simd.c:737-957) next to the trace arrays, so that the 3 x V x n bytes never
-// leave HBM: one wave stages a 64-node x 64-column window of source/esource/fsource in LDS, every lane follows the
+// leave HBM: one wave stages a 128-node x 64-column window of source/esource/fsource in LDS, every lane follows the
 // walk redundantly (wave-uniform control flow), lane 0 records one step per visited cell.  Cells outside the window
 // (far predecessors) are read from HBM.  Output: tsta_poa_step[] = {node, col, effective code, peek}.
 struct PoaWalkArgs {
     int V, n;
     const int* pred_off; const int* pred; const uint8_t* is_sink;
+    const int4* ptab;                    // [V]: the first four predecessors of every node (-1 padded): no dependent load when a window is staged
     const int8_t* source; const int8_t* esource; const int8_t* fsource; int64_t tpitch;
     const int* lastscore;
     tsta_poa_step* steps;                // out, capacity V + n + 2
     int* out;                            // out[0] = number of steps, out[1] = end column, out[2] = start node
 };
 
+constexpr int kWalkRows = 128;           // rows of the walker's window (the graph has ~2 nodes per column: rows run out first)
+typedef __attribute__((address_space(3))) const int8_t LdsI8;
+typedef __attribute__((address_space(1))) const int8_t GlobalI8;
+
 __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 {
-    __shared__ uint4 win[3][64][4];      // [array][row][64 bytes]
-    __shared__ int wpo[64], wnp[64], wpred[64][4];   // predecessor lists of the window's rows (first 4 of each)
+    __shared__ uint4 win[3][kWalkRows][4];      // [array][row][64 bytes]
+    __shared__ int wpo[kWalkRows], wnp[kWalkRows], wpred[kWalkRows][4];   // predecessor lists of the window's rows (first 4 of each)
+    __shared__ int wbb[kWalkRows];       // bit j: predecessor j of the row is the row just above it
     const int lane = threadIdx.x;
     // start: best sink among sort indices >= 1 (max lastsorce, lowest index on ties), else the last node (:737-750)
     int bv = INT_MIN, bi = -1;
@@ -454,16 +460,18 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     int num1 = __builtin_amdgcn_readfirstlane(bi >= 0 ? bi : A.V - 1);
     int num2 = A.n - 1, forced = -1, ns = 0;
     if (lane == 0) A.out[2] = num1;
+    LdsI8* wb = (LdsI8*)reinterpret_cast<const int8_t*>(win);
 
     while (num1 != -1 && num2 != -1) {
         // stage the window whose lower-right region holds (num1, num2)
-        const int rw0 = max(0, num1 - 63), cw0 = max(0, (num2 - 48) & ~15);
-        {
-            const int rr = rw0 + lane;
+        const int rw0 = max(0, num1 - (kWalkRows - 1)), cw0 = max(0, (num2 - 48) & ~15);
+#pragma unroll
+        for (int h = 0; h < kWalkRows / 64; ++h) {
+            const int wr = h * 64 + lane, rr = rw0 + wr;
             uint4 t[3][4];
-            // (the offsets of the rows' predecessor lists travel with the window loads: one round trip less)
             int po = 0, np_ = 0;
-            if (rr < A.V) { po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po; }
+            int4 pr = make_int4(-1, -1, -1, -1);
+            if (rr < A.V) { po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po; pr = A.ptab[rr]; }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
@@ -474,87 +482,76 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                                                             : make_uint4(0, 0, 0, 0);
                 }
             }
-            // the rows' predecessor lists: two dependent global loads per walk step otherwise
-            int pr[4] = {-1, -1, -1, -1};
-            if (rr < A.V) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (x < np_) pr[x] = A.pred[po + x];
-            }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) win[a][lane][x] = t[a][x];
-            wpo[lane] = po; wnp[lane] = np_;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) wpred[lane][x] = pr[x];
+                for (int x = 0; x < 4; ++x) win[a][wr][x] = t[a][x];
+            wpo[wr] = po; wnp[wr] = np_;
+            wpred[wr][0] = pr.x; wpred[wr][1] = pr.y; wpred[wr][2] = pr.z; wpred[wr][3] = pr.w;
+            wbb[wr] = (rr >= 1) ? ((pr.x == rr - 1 ? 1 : 0) | (pr.y == rr - 1 ? 2 : 0) | (pr.z == rr - 1 ? 4 : 0) | (pr.w == rr - 1 ? 8 : 0)) : 0;
         }
         __syncthreads();
-        const int8_t* wb = reinterpret_cast<const int8_t*>(win);
-        auto rd = [&](int a, int row, int col) -> int {      // trace byte of array a at (row, col)
-            const int off = col - cw0;                         // byte of the staged 64-byte piece of this row
-            if (row >= rw0 && row < rw0 + 64 && off >= 0 && off < 64)
-                return wb[(a * 64 + (row - rw0)) * 64 + off];
-            const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
-            return base[(size_t)row * A.tpitch + col];
+        // one trace byte of array a at a wave-uniform (row, col): from the window (the same LDS address in every lane) or,
+        // outside it, from memory; two separate loads (a select between the two addresses would make it a flat load)
+        auto rdu = [&](int a, int row, int col) -> int {
+            const int x = row - rw0, y = col - cw0;
+            int v;
+            if ((unsigned)x < (unsigned)kWalkRows && (unsigned)y < 64u) v = wb[(a * kWalkRows + x) * 64 + y];
+            else {
+                const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
+                v = *(GlobalI8*)(base + (size_t)row * A.tpitch + col);
+            }
+            return __builtin_amdgcn_readfirstlane(v);
         };
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
-            if (num1 < rw0 || num1 >= rw0 + 64 || num2 < cw0 || num2 >= cw0 + 64) break;   // restage
-            int probed_code = -1;                              // source code of (num1, num2) if the probe below has read it
+            const int wi = num1 - rw0, wc = num2 - cw0;
+            if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
+            int code;
             if (forced < 0) {
                 // ---- run of match / mismatch cells along the backbone, taken at once: lane l probes cell
                 // (num1 - l, num2 - l); the run continues while the cell is a diagonal move (:786-860, :861-956) whose
-                // predecessor is the row just above, all inside the window
-                const int r = num1 - lane, c = num2 - lane;
-                bool have = false, okc = false;
-                int code_l = 0;
-                if (r >= rw0 && c >= 0) {
-                    const int off = c - cw0;
-                    if (off >= 0 && off < 64) {
-                        have = true;
-                        code_l = wb[(0 * 64 + (r - rw0)) * 64 + off];
-                        const int kind_l = code_l / 42, pidx_l = code_l % 42;
-                        okc = (kind_l == 1 || kind_l == 2) && pidx_l < 4 && pidx_l < wnp[r - rw0] && r >= 1 &&
-                              wpred[r - rw0][pidx_l] == r - 1;
-                    }
-                }
+                // predecessor is the row just above, and while the cell after it (its "peek", :790,827,873) is in the window
+                const int x = wi - lane, y = wc - lane;
+                const bool have = x >= 0 && y >= 0;
+                int code_l = 0, bb = 0;
+                if (have) { code_l = wb[x * 64 + y]; bb = wbb[x]; }
+                const unsigned t = (unsigned)(code_l - 42);                    // 0..41 match, 42..83 mismatch
+                const int pidx_l = (int)(t < 42u ? t : t - 42u);
+                const bool okc = have && t < 84u && pidx_l < 4 && ((bb >> pidx_l) & 1) && ((x >= 1 && y >= 1 && lane < 63) || num2 - lane == 0);
                 const unsigned long long mask = __ballot(okc);
                 const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
                 if (run > 0) {
-                    const int nxt_code = __shfl_down(code_l, 1, 64);
-                    const int nxt_have = __shfl_down(have ? 1 : 0, 1, 64);
+                    const int nxt_code = __builtin_amdgcn_update_dpp(0, code_l, 0x130, 0xf, 0xf, false);   // lane l+1's (wave_shl:1)
                     if (lane < run) {
-                        int pk = 0;
-                        if (c - 1 >= 0) {
-                            const int cc = (lane < 63 && nxt_have) ? nxt_code : rd(0, r - 1, c - 1);
-                            pk = (cc / 42 == 1);
-                        }
-                        tsta_poa_step st; st.node = r; st.col = c; st.code = (int8_t)code_l; st.peek = (int8_t)pk; st.pad = 0;
+                        const int c = num2 - lane;
+                        tsta_poa_step st; st.node = num1 - lane; st.col = c; st.code = (int8_t)code_l;
+                        st.peek = (int8_t)((c > 0 && (unsigned)(nxt_code - 42) < 42u) ? 1 : 0); st.pad = 0;
                         A.steps[ns + lane] = st;
                     }
                     ns += run; num1 -= run; num2 -= run;
                     continue;
                 }
-                if (__builtin_amdgcn_readfirstlane(have ? 1 : 0)) probed_code = __builtin_amdgcn_readfirstlane(code_l);   // lane 0 probed (num1, num2) itself
-            }
-            int code;
-            if (forced >= 0) { code = forced; forced = -1; }
-            else code = probed_code >= 0 ? probed_code : __builtin_amdgcn_readfirstlane(rd(0, num1, num2));
+                code = __builtin_amdgcn_readfirstlane(code_l);                // lane 0 probed (num1, num2) itself
+            } else { code = forced; forced = -1; }
             const int kind = code / 42, pidx = code % 42;
-            const int wi = num1 - rw0;                          // in the window (checked above)
-            const int np = wnp[wi];
-            const int Psub = (pidx < np) ? (pidx < 4 ? wpred[wi][pidx] : A.pred[wpo[wi] + pidx]) : -1;
+            const int np = __builtin_amdgcn_readfirstlane(wnp[wi]);
+            int Psub = -1;
+            if (pidx < np) {
+                if (pidx < 4) Psub = __builtin_amdgcn_readfirstlane(wpred[wi][pidx]);
+                else Psub = __builtin_amdgcn_readfirstlane(A.pred[__builtin_amdgcn_readfirstlane(wpo[wi]) + pidx]);
+            }
             int peek = 0;
             int n1 = num1, n2 = num2;
             if (kind == 3) {                                   // F (:753-772)
-                const int fs = __builtin_amdgcn_readfirstlane(rd(2, num1, num2));
+                const int fs = rdu(2, num1, num2);
                 const int afs = fs < 0 ? -fs : fs;
-                if (num2 - 1 > 0 && (afs == 1 || (afs == 2 && __builtin_amdgcn_readfirstlane(rd(2, num1, num2 - 1)) < 0))) forced = 126;
+                if (num2 - 1 > 0 && (afs == 1 || (afs == 2 && rdu(2, num1, num2 - 1) < 0))) forced = 126;
                 n2 = num2 - 1;
             } else if (kind == 0) {                            // E (:773-785)
-                const int es = __builtin_amdgcn_readfirstlane(rd(1, num1, num2));
+                const int es = rdu(1, num1, num2);
                 if (Psub > 0) {
-                    const int esp = __builtin_amdgcn_readfirstlane(rd(1, Psub, num2));
+                    const int esp = rdu(1, Psub, num2);
                     if ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && esp < 0)) {
                         const int s5 = esp % 42;
                         forced = (s5 < 0 ? -s5 : s5) - 1;
@@ -562,7 +559,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 }
                 n1 = Psub;
             } else {                                           // match / mismatch (:786-860, :861-956)
-                if (Psub >= 0 && num2 - 1 >= 0) peek = (__builtin_amdgcn_readfirstlane(rd(0, Psub, num2 - 1)) / 42 == 1);
+                if (Psub >= 0 && num2 - 1 >= 0) peek = (rdu(0, Psub, num2 - 1) / 42 == 1);
                 n1 = Psub; n2 = num2 - 1;
             }
             if (lane == 0) {
@@ -668,7 +665,10 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
         }
         for (int k = 0; k < npred; ++k) pslot[k] = slot[dag->pred[k]];
     }
-    const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 8 + (size_t)V * 4 + (size_t)V * 2 + (size_t)n + 64;
+    std::vector<int> ptab((size_t)V * 4, -1);                  // first four predecessors per node (the walker's window staging)
+    for (int r = 0; r < V; ++r)
+        for (int k = dag->pred_off[r], x = 0; k < dag->pred_off[r + 1] && x < 4; ++k, ++x) ptab[(size_t)r * 4 + x] = dag->pred[k];
+    const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 8 + (size_t)V * 4 + (size_t)V * 2 + (size_t)n + 64 + (size_t)V * 16 + 16;
     const size_t rows_bytes = (size_t)nslots * pitch * sizeof(int);
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)", true)) ||
         (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)", true)) ||
@@ -686,19 +686,21 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     uint8_t* d_base = reinterpret_cast<uint8_t*>(d_slot + V);
     uint8_t* d_sink = d_base + V;
     uint8_t* d_seq = d_sink + V;
+    int* d_ptab = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(d_seq + n) + 15) & ~(uintptr_t)15);
     if ((rc = e->check(hipMemcpyAsync(d_off, dag->pred_off, (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s), "H2D pred_off")) ||
         (npred && (rc = e->check(hipMemcpyAsync(d_pred, dag->pred, (size_t)npred * 4, hipMemcpyHostToDevice, s), "H2D pred"))) ||
         (npred && (rc = e->check(hipMemcpyAsync(d_pslot, pslot.data(), (size_t)npred * 4, hipMemcpyHostToDevice, s), "H2D pred slots"))) ||
         (rc = e->check(hipMemcpyAsync(d_slot, slot.data(), (size_t)V * 4, hipMemcpyHostToDevice, s), "H2D slots")) ||
         (rc = e->check(hipMemcpyAsync(d_base, dag->base, V, hipMemcpyHostToDevice, s), "H2D base")) ||
         (rc = e->check(hipMemcpyAsync(d_sink, dag->is_sink, V, hipMemcpyHostToDevice, s), "H2D is_sink")) ||
-        (rc = e->check(hipMemcpyAsync(d_seq, seq, n, hipMemcpyHostToDevice, s), "H2D seq")))
+        (rc = e->check(hipMemcpyAsync(d_seq, seq, n, hipMemcpyHostToDevice, s), "H2D seq")) ||
+        (rc = e->check(hipMemcpyAsync(d_ptab, ptab.data(), (size_t)V * 16, hipMemcpyHostToDevice, s), "H2D pred table")))
         return rc;
     // the host vectors above must outlive the async copies
     if ((rc = e->check(hipStreamSynchronize(s), "poa upload sync"))) return rc;
 
     A.V = V; A.n = n; A.pred_off = d_off; A.pred = d_pred; A.base = d_base; A.is_sink = d_sink; A.seq = d_seq;
-    A.slot = d_slot; A.pred_slot = d_pslot;
+    A.slot = d_slot; A.pred_slot = d_pslot; A.ptab = d_ptab;
     A.Hrow = reinterpret_cast<int*>(e->rows.p);
     A.Erow = A.Hrow + (size_t)nslots * pitch;
     A.pitch = pitch;
@@ -794,7 +796,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     const size_t cap = (size_t)V + (size_t)n + 2;
     if ((rc = e->reserve(e->in_seqs, cap * sizeof(tsta_poa_step) + 64, "hipMalloc(poa steps)", true))) return rc;
     PoaWalkArgs Wk;
-    Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink;
+    Wk.V = V; Wk.n = n; Wk.pred_off = A.pred_off; Wk.pred = A.pred; Wk.is_sink = A.is_sink; Wk.ptab = reinterpret_cast<const int4*>(A.ptab);
     Wk.source = A.source; Wk.esource = A.esource; Wk.fsource = A.fsource; Wk.tpitch = A.tpitch;
     Wk.lastscore = A.lastscore;
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);

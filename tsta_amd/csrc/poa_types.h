@@ -20,6 +20,7 @@ struct PoaArgs {
     const uint8_t* seq;                  // n bytes
     const int* slot;                     // [V]: row slot of node r (slots are recycled once no later tile needs the row)
     const int* pred_slot;                // parallel to pred[]: slot of that predecessor
+    const int* ptab;                     // [V][4]: the first four predecessors of every node, -1 padded (the walker's window staging)
     int* Hrow;                           // [nslots][pitch]: Hrow[slot][c+3] = H(r,c), c = 0..n   (slot 0 = virtual init)
     int* Erow;                           // [nslots][pitch]: Erow[slot][c]   = Eagg(r,c+1), c = 0..n-1
     int64_t pitch;                       // ints per row, multiple of 4
