@@ -467,6 +467,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 const int sc0 = mt0 ? M : X, sc1 = mt1 ? M : X;
                 int bq0 = kNeg, bq1 = kNeg, be0 = kNeg, be1 = kNeg, jq0 = 0, jq1 = 0, je0 = 0, je1 = 0;
                 int hmx0 = kNeg, hmx1 = kNeg, hmn0 = -kNeg, hmn1 = -kNeg;
+                int dl[4] = {0, 0, 0, 0};                       // links: distance to predecessor j (0: not representable / not known)
                 // one predecessor's share: lowest predecessor index wins ties (strict >), je bit 6 = "the vertical gap opened"
                 auto take = [&](int j, int hl, int h0, int h1, int e0, int e1) {
                     const int qv0 = hl + sc0, qv1 = h0 + sc1;                                  // diagonal from H(p, c-1)
@@ -482,10 +483,14 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                     // every predecessor's record is in the ring: the reads of the first two go out together
                     PredVals va, vb;
                     int eda, edb = 0;
-                    { const int sl = ring_slot(__builtin_amdgcn_readlane(pr_b[0], i));
+                    { const int pa = __builtin_amdgcn_readlane(pr_b[0], i);
+                      const int sl = ring_slot(pa);
+                      dl[0] = (r - pa <= 31) ? r - pa : 0;
                       va.h0 = rec[sl][F_HS0][lane]; va.h1 = rec[sl][F_HS1][lane]; va.e0 = rec[sl][F_ES0][lane]; va.e1 = rec[sl][F_ES1][lane]; eda = side[S_EDGE][sl]; }
                     if (np > 1) {
-                        const int sl = ring_slot(__builtin_amdgcn_readlane(pr_b[1], i));
+                        const int pb = __builtin_amdgcn_readlane(pr_b[1], i);
+                        const int sl = ring_slot(pb);
+                        dl[1] = (r - pb <= 31) ? r - pb : 0;
                         vb.h0 = rec[sl][F_HS0][lane]; vb.h1 = rec[sl][F_HS1][lane]; vb.e0 = rec[sl][F_ES0][lane]; vb.e1 = rec[sl][F_ES1][lane]; edb = side[S_EDGE][sl];
                     }
                     {   // predecessor 0 (no comparison needed)
@@ -498,7 +503,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                     if (np > 1) {
                         take(1, df_shr1(edb, vb.h1), vb.h0, vb.h1, vb.e0, vb.e1);
                         for (int j = 2; j < np; ++j) {
-                            const int sl = ring_slot(j == 2 ? __builtin_amdgcn_readlane(pr_b[2], i) : __builtin_amdgcn_readlane(pr_b[3], i));
+                            const int pj = (j == 2) ? __builtin_amdgcn_readlane(pr_b[2], i) : __builtin_amdgcn_readlane(pr_b[3], i);
+                            const int sl = ring_slot(pj);
+                            if (j == 2) dl[2] = (r - pj <= 31) ? r - pj : 0; else dl[3] = (r - pj <= 31) ? r - pj : 0;
                             const int h0 = rec[sl][F_HS0][lane], h1 = rec[sl][F_HS1][lane], e0 = rec[sl][F_ES0][lane], e1 = rec[sl][F_ES1][lane];
                             take(j, df_shr1(side[S_EDGE][sl], h1), h0, h1, e0, e1);
                         }
@@ -542,7 +549,21 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                 const int ep0 = ((je0 & 64) ? 43 : 1) + (je0 & 63), ep1 = ((je1 & 64) ? 43 : 1) + (je1 & 63);       // c-t-simd.c:530-538
                 const int ec0 = (es0 + E == hOE0) ? -ep0 : ep0, ec1 = (es1 + E == hOE1) ? -ep1 : ep1;
                 const int fp0 = opn0 + 1, fp1 = opn1 + 1;                                   // c-t-simd.c:521-522,564-565
-                const int fc0 = (fl0 + E == hOE0) ? -fp0 : fp0, fc1 = (fl1 + E == hOE1) ? -fp1 : fp1;
+                int fc0 = (fl0 + E == hOE0) ? -fp0 : fp0, fc1 = (fl1 + E == hOE1) ? -fp1 : fp1;
+                if (A.links) {
+                    // the cell's own move goes to predecessor jq (diagonal) or je (vertical gap): its distance rides on the F code
+                    const int s0i = (bq0 == hs0) ? jq0 : (je0 & 63), s1i = (bq1 == hs1) ? jq1 : (je1 & 63);
+                    int d0 = dl[0], d1 = dl[0];
+                    if (np > 1) {
+                        d0 = (s0i == 1) ? dl[1] : d0; d1 = (s1i == 1) ? dl[1] : d1;
+                        if (np > 2) {
+                            d0 = (s0i == 2) ? dl[2] : d0; d1 = (s1i == 2) ? dl[2] : d1;
+                            d0 = (s0i == 3) ? dl[3] : d0; d1 = (s1i == 3) ? dl[3] : d1;
+                            d0 = (s0i > 3) ? 0 : d0; d1 = (s1i > 3) ? 0 : d1;
+                        }
+                    }
+                    fc0 = (fc0 & 7) | (d0 << 3); fc1 = (fc1 & 7) | (d1 << 3);
+                }
                 const unsigned w1 = (unsigned)(code0 & 0xff) | ((unsigned)(code1 & 0xff) << 8);
                 const unsigned w2 = (unsigned)(ec0 & 0xff) | ((unsigned)(ec1 & 0xff) << 8);
                 const unsigned w3 = (unsigned)(fc0 & 0xff) | ((unsigned)(fc1 & 0xff) << 8);

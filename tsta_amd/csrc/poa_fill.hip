@@ -442,6 +442,10 @@ constexpr int kWalkRows = 128;           // rows of the walker's window (the gra
 typedef __attribute__((address_space(3))) const int8_t LdsI8;
 typedef __attribute__((address_space(1))) const int8_t GlobalI8;
 
+// LINKS: the fill left, above the 3 bits of every F code, the distance to the predecessor the cell's own move goes to
+// (PoaArgs::links): a step is then one LDS round — the cell's source and fsource bytes — and the "peek" of a diagonal step is
+// the source byte the NEXT step reads anyway.
+template <bool LINKS>
 __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 {
     __shared__ uint4 win[3][kWalkRows][4];      // [array][row][64 bytes]
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     int num1 = __builtin_amdgcn_readfirstlane(bi >= 0 ? bi : A.V - 1);
     int num2 = A.n - 1, forced = -1, ns = 0;
     if (lane == 0) A.out[2] = num1;
+    bool pend = false; int pend_node = 0, pend_col = 0, pend_code = 0, pend_idx = 0;     // LINKS: diagonal step waiting for its peek
     LdsI8* wb = (LdsI8*)reinterpret_cast<const int8_t*>(win);
 
     while (num1 != -1 && num2 != -1) {
@@ -507,6 +512,63 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             if (num1 == -1 || num2 == -1) break;
             const int wi = num1 - rw0, wc = num2 - cw0;
             if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
+            if constexpr (LINKS) {
+                const int sb = __builtin_amdgcn_readfirstlane((int)wb[wi * 64 + wc]);
+                const int fb = __builtin_amdgcn_readfirstlane((int)wb[(2 * kWalkRows + wi) * 64 + wc]);
+                if (pend) {                                    // the step before was a diagonal move to this cell
+                    if (lane == 0) {
+                        tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code;
+                        st.peek = (int8_t)(((unsigned)(sb - 42) < 42u) ? 1 : 0); st.pad = 0;
+                        A.steps[pend_idx] = st;
+                    }
+                    pend = false;
+                }
+                const bool was_forced = forced >= 0;
+                const int code = was_forced ? forced : sb;
+                forced = -1;
+                const int kind = code / 42, pidx = code % 42;
+                int Psub = -1;
+                const int d = (fb >> 3) & 31;
+                if (kind != 3) {
+                    if (!was_forced && d != 0) Psub = num1 - d;
+                    else {
+                        const int np = __builtin_amdgcn_readfirstlane(wnp[wi]);
+                        if (pidx < np) {
+                            if (pidx < 4) Psub = __builtin_amdgcn_readfirstlane(wpred[wi][pidx]);
+                            else Psub = __builtin_amdgcn_readfirstlane(A.pred[__builtin_amdgcn_readfirstlane(wpo[wi]) + pidx]);
+                        }
+                    }
+                }
+                int n1 = num1, n2 = num2;
+                bool defer = false;
+                if (kind == 3) {                                   // F (:753-772); the F code is the low 3 bits
+                    const int fs = (int)((unsigned)fb << 29) >> 29;
+                    const int afs = fs < 0 ? -fs : fs;
+                    if (num2 - 1 > 0 && (afs == 1 || (afs == 2 && ((int)((unsigned)rdu(2, num1, num2 - 1) << 29) >> 29) < 0))) forced = 126;
+                    n2 = num2 - 1;
+                } else if (kind == 0) {                            // E (:773-785)
+                    const int es = rdu(1, num1, num2);
+                    if (Psub > 0) {
+                        const int esp = rdu(1, Psub, num2);
+                        if ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && esp < 0)) {
+                            const int s5 = esp % 42;
+                            forced = (s5 < 0 ? -s5 : s5) - 1;
+                        }
+                    }
+                    n1 = Psub;
+                } else {                                           // match / mismatch (:786-860, :861-956)
+                    defer = (Psub >= 0 && num2 - 1 >= 0);          // its peek is the source byte of the next cell
+                    n1 = Psub; n2 = num2 - 1;
+                }
+                if (defer) { pend = true; pend_node = num1; pend_col = num2; pend_code = code; pend_idx = ns; }
+                else if (lane == 0) {
+                    tsta_poa_step st; st.node = num1; st.col = num2; st.code = (int8_t)code; st.peek = 0; st.pad = 0;
+                    A.steps[ns] = st;
+                }
+                ++ns;
+                num1 = n1; num2 = n2;
+                continue;
+            }
             int code;
             if (forced < 0) {
                 // ---- run of match / mismatch cells along the backbone, taken at once: lane l probes cell
@@ -571,6 +633,10 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         }
         __syncthreads();
     }
+    if (pend && lane == 0) {                                   // (cannot happen: a deferred step always has a next cell)
+        tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code; st.peek = 0; st.pad = 0;
+        A.steps[pend_idx] = st;
+    }
     if (lane == 0) { A.out[0] = ns; A.out[1] = num2; }
 }
 
@@ -617,7 +683,7 @@ static int poa_dataflow_status(Engine* e)
 
 // Validation, uploads, workspace and the fill launches; leaves everything on the device.
 static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq, int32_t n,
-                             bool want_trace, PoaArgs& A)
+                             bool want_trace, PoaArgs& A, bool for_walk = false)
 {
     const int V = dag->n_nodes;
     const int npred = dag->pred_off[V];
@@ -714,6 +780,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.lastscore = reinterpret_cast<int*>(e->out_scores.p);
     A.best = reinterpret_cast<int*>(e->counter.p);
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
+    A.links = 0;
 
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
     const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && nchunks < e->n_cu && memchr(seq, 'N', (size_t)n) == nullptr;
@@ -721,6 +788,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
     int launches = 1;
     if (dataflow) {
+        A.links = for_walk ? 1 : 0;                           // (the arrays stay on the device: fsource may carry the walker's links)
         const size_t per = (size_t)V * (nchunks + 1);
         int* d_hand = A.carry + ((per + 3) & ~(size_t)3);    // [V][nchunks+1][4], 16-byte aligned
         int* d_work = d_hand + 4 * per;
@@ -790,7 +858,7 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     if (V == 0 || n == 0) return TSTA_OK;
     if (!dag->pred_off || !dag->base || !dag->is_sink || !seq) return TSTA_ERR_INVALID_ARG;
     PoaArgs A;
-    int rc = poa_run_on_device(e, p, dag, seq, n, true, A);
+    int rc = poa_run_on_device(e, p, dag, seq, n, true, A, true);
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
     const size_t cap = (size_t)V + (size_t)n + 2;
@@ -801,7 +869,8 @@ extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta
     Wk.lastscore = A.lastscore;
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
     Wk.out = A.best + 4;
-    hipLaunchKernelGGL(poa_walk_kernel, dim3(1), dim3(64), 0, s, Wk);
+    if (A.links) hipLaunchKernelGGL(poa_walk_kernel<true>, dim3(1), dim3(64), 0, s, Wk);
+    else hipLaunchKernelGGL(poa_walk_kernel<false>, dim3(1), dim3(64), 0, s, Wk);
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;

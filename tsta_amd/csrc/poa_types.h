@@ -32,6 +32,9 @@ struct PoaArgs {
     int* lastscore;                      // [V]
     int* best;                           // [0] = best sink; [4..7] walker results; [8] = largest spread seen between two predecessor rows of a node
     int M, X, E, O;
+    int links;                           // 1: fsource bytes carry, above the F code's 3 bits, the distance (1..31 rows, 0 = look it up) to the
+                                         // predecessor the cell's own move goes to: the on-device walk then needs no predecessor list (K4d only;
+                                         // never set when the arrays go back to the caller)
 };
 
 
