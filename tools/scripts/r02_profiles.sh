@@ -2,7 +2,7 @@
 # the other configs with their kernel stats
 set -e
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02m; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O; cd $R
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"; tail -c 400 $O/bench_default.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-generic --no-related --no-verify > $O/bench_prof.json 2> $O/prof.err

@@ -439,6 +439,12 @@ struct PoaWalkArgs {
 };
 
 constexpr int kWalkRows = 128;           // rows of the walker's window (the graph has ~2 nodes per column: rows run out first)
+// one lane of a VGPR from scalar registers (lane select through m0: two different SGPRs would exceed the constant bus; the
+// compiler keeps nothing in m0 across statements on gfx9+, it loads it right before the few instructions that read it)
+__device__ __forceinline__ void wlane(int& v, int val, int idx)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(idx)));
+}
 typedef __attribute__((address_space(3))) const int8_t LdsI8;
 typedef __attribute__((address_space(1))) const int8_t GlobalI8;
 
@@ -510,9 +516,42 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         };
         for (;;) {
             if (num1 == -1 || num2 == -1) break;
-            const int wi = num1 - rw0, wc = num2 - cw0;
+            int wi = num1 - rw0, wc = num2 - cw0;
             if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
             if constexpr (LINKS) {
+                if (forced < 0) {
+                    // ---- consecutive diagonal steps inside the window: the steps are collected in lanes (v_writelane) and stored
+                    // 64 at a time; a step's peek is known one step later, so its code word is written then
+                    int bufN = 0, bufC = 0, bufW = 0;
+                    int k = 0, base_idx = ns, prev_code = 0;
+                    if (pend) { wlane(bufN, pend_node, 0); wlane(bufC, pend_col, 0); prev_code = pend_code; base_idx = pend_idx; k = 1; pend = false; }
+                    int a = wi * 64 + wc;                        // byte of the cell in the window's source array
+                    int why;                                     // 0: the cell is not a linked diagonal move, 1: left the window / buffer full, 2: the walk is over
+                    for (;;) {
+                        const int sb = __builtin_amdgcn_readfirstlane((int)wb[a]);
+                        const int fb = __builtin_amdgcn_readfirstlane((int)wb[2 * kWalkRows * 64 + a]);
+                        if (k > 0) wlane(bufW, prev_code | (((unsigned)(sb - 42) < 42u) ? 256 : 0), k - 1);
+                        const int d = (fb >> 3) & 31;
+                        if ((unsigned)(sb - 42) >= 84u || d == 0) { why = 0; break; }
+                        wlane(bufN, num1, k); wlane(bufC, num2, k); prev_code = sb; ++k; ++ns;
+                        num1 -= d; num2 -= 1; a -= d * 64 + 1;
+                        if (num2 < 0) { wlane(bufW, prev_code, k - 1); why = 2; break; }            // (no next cell: peek 0)
+                        if (num1 < rw0 || num2 < cw0 || k == 64) { why = 1; break; }
+                    }
+                    // entries 0 .. k-1 are complete, except the last one when the loop stopped for the window / the buffer
+                    int done = k;
+                    if (why == 1) {
+                        done = k - 1;
+                        pend = true; pend_node = __builtin_amdgcn_readlane(bufN, k - 1); pend_col = __builtin_amdgcn_readlane(bufC, k - 1);
+                        pend_code = prev_code; pend_idx = base_idx + k - 1;
+                    }
+                    if (lane < done) {
+                        tsta_poa_step st; st.node = bufN; st.col = bufC; st.code = (int8_t)(bufW & 0xff); st.peek = (int8_t)(bufW >> 8); st.pad = 0;
+                        A.steps[base_idx + lane] = st;
+                    }
+                    if (why != 0) continue;
+                    wi = num1 - rw0; wc = num2 - cw0;            // (the cell the loop stopped at: still inside the window)
+                }
                 const int sb = __builtin_amdgcn_readfirstlane((int)wb[wi * 64 + wc]);
                 const int fb = __builtin_amdgcn_readfirstlane((int)wb[(2 * kWalkRows + wi) * 64 + wc]);
                 if (pend) {                                    // the step before was a diagonal move to this cell
