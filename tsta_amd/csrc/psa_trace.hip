@@ -439,6 +439,14 @@ struct WalkArgs {
     int* out;            // out[2] = number of ops emitted, out[3] = final i, out[4] = final j
 };
 
+// (global address space spelled out: the pointers come out of a struct in memory, the compiler would emit flat loads, and a flat
+// load in flight makes every LDS wait of the walk wait for it too)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4_t GlobalConstU4;
+__device__ __forceinline__ uint4 ld_global_u4(GlobalConstU4* p) { const u32x4_t v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
+typedef __attribute__((address_space(1))) const uint8_t GlobalConstU8;
+typedef __attribute__((address_space(1))) uint8_t GlobalU8;
+
 template <int R, int NQ>
 __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
 {
@@ -454,21 +462,52 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
     int i = A.m, j = A.n;            // 1-based current cell (wave-uniform)
     int forced = -1;
     int cnt = 0;
+    // The window the walk will need NEXT is loaded while it crosses the current one (the trace is cold in HBM: ~2-3 us per
+    // window otherwise, one window per band of a mostly diagonal walk): `pre` holds step groups [pre_qlo, pre_qhi] of band pre_w.
+    uint4 pre[NQ];
+    int pre_w = -1, pre_qlo = 0, pre_qhi = -1;
+    const int groups_per_band = (int)(A.band_bytes / (64 * 16));
     while (i >= 1 && j >= 1) {
         // stage the window that ends at the current cell's step group (one band, NQ step groups of 1 KiB)
         const int w = (i - 1) / BAND;
         const int ln = ((i - 1) % BAND) / R;
-        const int qhi = (j - 1 + ln) / SPB;
-        const int qlo = max(0, qhi - (NQ - 1));
-        const uint4* src = reinterpret_cast<const uint4*>(A.trace + (size_t)w * A.band_bytes) + (size_t)qlo * 64;
-        const int nq = qhi - qlo + 1;
-        {
-            // all loads of the window in flight at once (the trace is cold in HBM: ~2 us per dependent round trip)
+        const int q_need = (j - 1 + ln) / SPB;
+        int qlo, qhi;
+        if (w == pre_w && q_need <= pre_qhi && q_need - pre_qlo >= 4) {
+            qlo = pre_qlo; qhi = pre_qhi;                       // predicted well enough: no load on the path
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) win[x * 64 + lane] = pre[x];
+        } else {
+            qhi = q_need; qlo = max(0, qhi - (NQ - 1));
+            GlobalConstU4* src = (GlobalConstU4*)(reinterpret_cast<const uint4*>(A.trace + (size_t)w * A.band_bytes) + (size_t)qlo * 64);
+            const int nq = qhi - qlo + 1;
+            // all loads of the window in flight at once
             uint4 tmp[NQ];
 #pragma unroll
-            for (int x = 0; x < NQ; ++x) tmp[x] = (x < nq) ? src[x * 64 + lane] : make_uint4(0, 0, 0, 0);
+            for (int x = 0; x < NQ; ++x) tmp[x] = (x < nq) ? ld_global_u4(src + x * 64 + lane) : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int x = 0; x < NQ; ++x) win[x * 64 + lane] = tmp[x];
+        }
+        {
+            // the next window, assuming the walk goes on diagonally: the band above if this window reaches the band's first row,
+            // else the step groups just below this window (a walk leaves a window at step group qlo - 1 exactly)
+            const int rows_left = i - w * BAND;                 // diagonal steps until row w*BAND (the last row of the band above)
+            const int j_top = j - rows_left + 1;                // column of the band's first row on that diagonal
+            const bool exits_band = j_top < 1 || (j_top - 1) / SPB >= qlo;
+            if (exits_band && w >= 1) {
+                pre_w = w - 1;
+                pre_qhi = min(groups_per_band - 1, (max(j_top - 1, 1) - 1 + 63) / SPB + 4);      // (margin: gaps shift the crossing)
+            } else if (!exits_band && qlo >= 1) {
+                pre_w = w;
+                pre_qhi = qlo - 1;
+            } else pre_w = -1;
+            if (pre_w >= 0) {
+                pre_qlo = max(0, pre_qhi - (NQ - 1));
+                GlobalConstU4* src = (GlobalConstU4*)(reinterpret_cast<const uint4*>(A.trace + (size_t)pre_w * A.band_bytes) + (size_t)pre_qlo * 64);
+                const int nq = pre_qhi - pre_qlo + 1;
+#pragma unroll
+                for (int x = 0; x < NQ; ++x) pre[x] = (x < nq) ? ld_global_u4(src + x * 64 + lane) : make_uint4(0, 0, 0, 0);
+            }
         }
         __syncthreads();
         const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
@@ -477,8 +516,9 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
             const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
             const int ct = cj - 1 + cl, cq = ct / SPB;
             const size_t off = ((size_t)cq * 64 + cl) * 16 + (ct % SPB) * R + ck;
-            if (cw == w && cq >= qlo && cq <= qhi) return wb[off - (size_t)qlo * 64 * 16];
-            return A.trace[(size_t)cw * A.band_bytes + off];
+            // (made uniform inside each branch: the LDS path then waits for the LDS only, not for the prefetch in flight)
+            if (cw == w && cq >= qlo && cq <= qhi) return (unsigned)__builtin_amdgcn_readfirstlane((int)wb[off - (size_t)qlo * 64 * 16]);
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)*(GlobalConstU8*)(A.trace + (size_t)cw * A.band_bytes + off));
         };
         for (;;) {
             if (i < 1 || j < 1) break;
@@ -502,7 +542,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                 const unsigned long long mask = __ballot(isdiag);
                 const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
                 if (run > 0) {
-                    if (lane < run) A.ops[cnt + lane] = 1;
+                    if (lane < run) *(GlobalU8*)(A.ops + cnt + lane) = 1;
                     i -= run; j -= run; cnt += run;
                     continue;
                 }
@@ -512,7 +552,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
             int k;
             if (forced >= 0) { k = forced; forced = -1; }
             else k = !(c & 1u) ? 1 : (!(c & 2u) ? 0 : 2);         // psa.c:443-455: diag > left > up
-            if (lane == 0) A.ops[cnt] = (uint8_t)k;
+            if (lane == 0) *(GlobalU8*)(A.ops + cnt) = (uint8_t)k;
             ++cnt;
             if (k == 1) { --i; --j; }
             else if (k == 0) {
