@@ -520,6 +520,20 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
             if (cw == w && cq >= qlo && cq <= qhi) return (unsigned)__builtin_amdgcn_readfirstlane((int)wb[off - (size_t)qlo * 64 * 16]);
             return (unsigned)__builtin_amdgcn_readfirstlane((int)*(GlobalConstU8*)(A.trace + (size_t)cw * A.band_bytes + off));
         };
+        // byte of cell (ci,cj) inside the staged window, or -1
+        auto win_off = [&](int ci, int cj) -> int {
+            const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
+            const int ct = cj - 1 + cl, cq = ct / SPB;
+            return (cw == w && cq >= qlo && cq <= qhi) ? ((cq - qlo) * 64 + cl) * 16 + (ct % SPB) * R + ck : -1;
+        };
+        // two cells at once (the gap rules look at the next two cells in the gap's direction): both LDS reads go out together
+        auto code2 = [&](int ai, int aj, int bi, int bj, unsigned& ca, unsigned& cb) {
+            const int oa = win_off(ai, aj), ob = win_off(bi, bj);
+            if (oa >= 0 && ob >= 0) {
+                const int va = wb[oa], vb = wb[ob];
+                ca = (unsigned)__builtin_amdgcn_readfirstlane(va); cb = (unsigned)__builtin_amdgcn_readfirstlane(vb);
+            } else { ca = code(ai, aj); cb = code(bi, bj); }
+        };
         for (;;) {
             if (i < 1 || j < 1) break;
             {
@@ -527,16 +541,19 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                 const int cq = (j - 1 + cl) / SPB;
                 if (cw != w || cq < qlo) break;                  // left the window: restage
             }
+            unsigned c = 0;
             if (forced < 0) {
                 // ---- diagonal run: lane l probes cell (i-l, j-l); the run of leading "diag" cells is taken at once
                 const int ci = i - lane, cj = j - lane;
                 bool isdiag = false;
+                int byte_l = 0;
                 if (ci >= 1 && cj >= 1) {
                     const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
                     const int ct = cj - 1 + cl, cq = ct / SPB;
                     if (cw == w && cq >= qlo) {
                         const size_t off = ((size_t)(cq - qlo) * 64 + cl) * 16 + (ct % SPB) * R + ck;
-                        isdiag = !(wb[off] & 1u);                 // psa.c:443: back == 1
+                        byte_l = wb[off];
+                        isdiag = !(byte_l & 1u);                  // psa.c:443: back == 1
                     }
                 }
                 const unsigned long long mask = __ballot(isdiag);
@@ -546,9 +563,9 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                     i -= run; j -= run; cnt += run;
                     continue;
                 }
+                c = (unsigned)__builtin_amdgcn_readfirstlane(byte_l);     // lane 0 probed (i, j) itself (inside the window)
             }
-            // ---- one non-diagonal (or forced) step, computed identically by every lane
-            const unsigned c = __builtin_amdgcn_readfirstlane(code(i, j));
+            // ---- one non-diagonal (or forced) step, computed identically by every lane (a forced step does not look at its cell)
             int k;
             if (forced >= 0) { k = forced; forced = -1; }
             else k = !(c & 1u) ? 1 : (!(c & 2u) ? 0 : 2);         // psa.c:443-455: diag > left > up
@@ -559,21 +576,21 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                 // psa.c:450-452: continue left if F(i,j) was an extension, or it was opened and the cell to the
                 // left is "opened & tied"
                 if (j - 1 >= 1) {
-                    const unsigned cl1 = __builtin_amdgcn_readfirstlane(code(i, j - 1));
+                    unsigned cl1, cl2 = ~0u;
+                    if (j - 1 != 1) code2(i, j - 1, i, j - 2, cl1, cl2); else cl1 = code(i, j - 1);
                     const bool fopen_ij = ((cl1 >> 2) & 3u) >= 1u;                       // Fopen(i,j) stored at (i,j-1)
                     const bool ftie_l = ((cl1 >> 2) & 3u) == 1u;                         // Ftie(i,j-1)
-                    bool fopen_l = true;                                                 // Fopen(i,j-1)
-                    if (j - 1 != 1) fopen_l = ((__builtin_amdgcn_readfirstlane(code(i, j - 2)) >> 2) & 3u) >= 1u;
+                    const bool fopen_l = (j - 1 != 1) ? (((cl2 >> 2) & 3u) >= 1u) : true;   // Fopen(i,j-1)
                     if (!fopen_ij || (fopen_l && ftie_l)) forced = 0;
                 }
                 --j;
             } else {
                 if (i - 1 >= 1) {                                                       // psa.c:457-459
-                    const unsigned cu1 = __builtin_amdgcn_readfirstlane(code(i - 1, j));
+                    unsigned cu1, cu2 = ~0u;
+                    if (i - 1 != 1) code2(i - 1, j, i - 2, j, cu1, cu2); else cu1 = code(i - 1, j);
                     const bool eopen_ij = ((cu1 >> 4) & 3u) >= 1u;                       // Eopen(i,j) stored at (i-1,j)
                     const bool etie_u = ((cu1 >> 4) & 3u) == 1u;                         // Etie(i-1,j)
-                    bool eopen_u = true;                                                 // Eopen(i-1,j)
-                    if (i - 1 != 1) eopen_u = ((__builtin_amdgcn_readfirstlane(code(i - 2, j)) >> 4) & 3u) >= 1u;
+                    const bool eopen_u = (i - 1 != 1) ? (((cu2 >> 4) & 3u) >= 1u) : true;   // Eopen(i-1,j)
                     if (!eopen_ij || (eopen_u && etie_u)) forced = 2;
                 }
                 --i;
