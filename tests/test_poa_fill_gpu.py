@@ -88,6 +88,23 @@ def test_four_columns_per_lane_variant(eng):
         eng.set_option("poa_cols", 0)
 
 
+def test_abandoned_single_launch_is_run_again(eng):
+    # the single-launch fill needs all its workgroups resident; a launch that abandons its waits is repeated through the
+    # launch-per-diagonal form by the entry points themselves ("poa_dataflow" = 2 reports every launch as abandoned once)
+    z, sc = load(FIXTURES[0])
+    args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+    want = eng.poa_fill(*args, tsta_amd.Params(**sc))
+    want_steps, want_end, _ = eng.poa_align(*args, tsta_amd.Params(**sc))
+    try:
+        eng.set_option("poa_dataflow", 2)
+        got = eng.poa_fill(*args, tsta_amd.Params(**sc))
+        steps, end_col, _ = eng.poa_align(*args, tsta_amd.Params(**sc))
+    finally:
+        eng.set_option("poa_dataflow", 1)
+    assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
+    assert end_col == want_end and np.array_equal(steps, want_steps)
+
+
 def test_launch_per_diagonal_variant(eng):
     # the default for these sizes is the single-launch dataflow fill (poa_dataflow.hip: solver + emitter waves); the
     # launch-per-anti-diagonal K4 (which also serves sequences with 'N' and > 32 640 columns) must give the same bytes
