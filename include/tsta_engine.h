@@ -76,10 +76,10 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "trace_lds"        1 (default): single-pair trace fill hands the bottom row of three of every four bands to the next band
  *                      through LDS rings inside a workgroup (psa_trace_quad_kernel) | 0: every hand-off through memory
  *   "poa_dataflow"     1 (default): POA fill as one launch, one workgroup per 128-column chunk with a solver wave, four emitter
- *                      waves and a fetcher wave (poa_dataflow.hip; sequences <= 32 640 without 'N').  All its workgroups must be
- *                      resident; should a launch abandon its waits (a chip shared with other kernels), the call is run again
- *                      through the other form | 0: always one launch per tile anti-diagonal | 2: as 1, and every call is treated
- *                      as abandoned once (tests of that second run)
+ *                      waves and a fetcher wave (poa_dataflow.hip; sequences without 'N').  Roles are tickets drawn in start
+ *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
+ *                      waits all the same, the call is run again through the other form | 0: always one launch per tile
+ *                      anti-diagonal | 2: as 1, and every call is treated as abandoned once (tests of that second run)
  *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against
  *                      (default 640 = AVX512 x -W 10; the TSTA_msa drop-in passes 64 x its -W); multiple of 16, 16 .. 1048576
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */

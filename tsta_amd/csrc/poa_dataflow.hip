@@ -9,8 +9,9 @@
 //  1. One workgroup per chunk of 128 columns, one launch.  Workgroup q sweeps ALL the nodes of its chunk, 32 at a time (a
 //     "block"); it takes over, per row, three values from the chunk on its left (F carry, open flag, H at the edge: `hand`,
 //     sc1 stores / loads, handoff.h) once that chunk has published the block (prog[q]), and publishes its own.  A workgroup
-//     waits only for its left neighbour and all of them are resident, so the waits always end.  Column 0 — H(r, 0), a function
-//     of the graph alone — is one more workgroup (a single wave) that plays "left neighbour" for chunk 0.
+//     waits only for its left neighbour, and roles are tickets drawn in the order the workgroups start (the neighbour is always
+//     already running): the waits end whatever the dispatch order or the residency.  Column 0 — H(r, 0), a function of the
+//     graph alone — is one more workgroup (a single wave) that plays "left neighbour" for chunk 0.
 //  2. Roles.  Wave 0, the SOLVER, runs only what the next row needs — predecessor maxima, the max-plus scan of F, final
 //     H / Eagg / F — and leaves six dwords per lane and row in an LDS ring of three blocks: ~55 instructions per backbone row
 //     (one predecessor = the row before, tight loop), ~100 for a row with several / non-adjacent predecessors whose records
@@ -21,8 +22,8 @@
 //  3. Nobody waits at a barrier: records are followed by a counter (the LDS performs one wave's operations in order), a block
 //     is published by whichever wave finishes it last.
 //
-// Scope: 2 columns per lane, one chunk per CU (sequences up to 255 x 128 = 32 640 columns) and sequences without a literal 'N' (the N-column rule needs the
-// segment-by-segment scan of poa_fill.hip); everything else runs the launch-per-diagonal K4.
+// Scope: 2 columns per lane, any length (with more chunks than CUs the later ones start as CUs come free), sequences without a
+// literal 'N' (the N-column rule needs the segment-by-segment scan of poa_fill.hip: those run the launch-per-diagonal K4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
@@ -145,9 +146,14 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 
     if (threadIdx.x == 0) { blk_pub = 0; fetched = 0; taken = 0; blk_done[0] = blk_done[1] = blk_done[2] = blk_done[3] = 0; }
     if (threadIdx.x < 64) produced[threadIdx.x] = 0;
+    // Roles are handed out as tickets in the order the workgroups actually start (HIP promises no dispatch order): ticket 0 is
+    // column 0, ticket t chunk t-1.  A workgroup only ever waits for the holder of the ticket before its own, which is already
+    // running: no deadlock whatever the residency — with more chunks than CUs the later chunks simply start as CUs come free.
+    __shared__ int ticket_s;
+    if (threadIdx.x == 0) ticket_s = (int)atomicAdd(P.ticket, 1u);
     __syncthreads();
-    const int q = blockIdx.x;                            // this workgroup's chunk; workgroup nchunks is the column-0 solver below
-    if (q == A.nchunks) {
+    const int q = __builtin_amdgcn_readfirstlane(ticket_s) - 1;      // this workgroup's chunk; -1: the column-0 solver below
+    if (q < 0) {
         // ================================================================ column 0 (c-t-simd.c:174-188, 194-200)
         // H(r, 0) = max over predecessors H(p, 0) + E (a source: O + E) depends on the graph only.  One wave walks the nodes
         // ahead of chunk 0 and hands it, per row, what every other chunk gets from the chunk on its left: the F carry
@@ -616,12 +622,12 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s)
 {
     const size_t head = 16 + (size_t)A.nchunks + 1;
-    if (head > work_ints || A.nchunks + 1 > e->n_cu) return TSTA_ERR_INTERNAL;   // every workgroup must be resident: one per CU
+    if (head > work_ints) return TSTA_ERR_INTERNAL;
     int rc;
     if ((rc = e->check(hipMemsetAsync(d_work, 0, head * sizeof(int), s), "hipMemsetAsync(poa dataflow)"))) return rc;
     PoaDfArgs P;
     P.A = A;
-    P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
+    P.ticket = reinterpret_cast<unsigned*>(d_work); P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
     P.hand = d_hand;
     hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks + 1), dim3(kDfThreads), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");

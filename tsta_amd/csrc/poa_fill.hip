@@ -743,9 +743,9 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
 
     // 4 columns per lane (256-column tiles) are cheaper per cell; 2 per lane put twice as many tiles in flight,
     // which wins while the sequence is short enough that the tile wavefront is the limit
-    // (2 per lane also while the single-launch form fits: one 128-column chunk per CU, one CU left for column 0)
+    // (2 per lane whenever the single-launch form serves the call)
     const int kc = (e->opt_poa_cols == 2 || e->opt_poa_cols == 4) ? e->opt_poa_cols
-                 : (n <= 16384 || (e->opt_poa_dataflow && n <= 128 * (e->n_cu - 1) && memchr(seq, 'N', (size_t)n) == nullptr) ? 2 : 4);
+                 : (n <= 16384 || (e->opt_poa_dataflow && memchr(seq, 'N', (size_t)n) == nullptr) ? 2 : 4);
     const int cw = 64 * kc;
     const int nchunks = (n + cw - 1) / cw, nrb = (V + kRB - 1) / kRB;
     const int64_t pitch = ((int64_t)nchunks * cw + 8 + 3) / 4 * 4 + 8;
@@ -827,7 +827,7 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.links = 0;
 
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
-    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && nchunks < e->n_cu && memchr(seq, 'N', (size_t)n) == nullptr;
+    const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && memchr(seq, 'N', (size_t)n) == nullptr;
     e->timing_begin(s);
     hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (n + 256) / 256)), dim3(256), 0, s, A);
     int launches = 1;

@@ -41,6 +41,7 @@ struct PoaArgs {
 // poa_dataflow.hip: the single-launch fill (one workgroup per 128-column chunk, solver + emitter waves)
 struct PoaDfArgs {
     PoaArgs A;
+    unsigned* ticket;                    // [1]: roles in start order (0: column 0, t: chunk t-1)
     unsigned* status;
     int* prog;                           // [nchunks+1]: blocks of 32 nodes completed by the column-0 solver ([0]) and by chunk q ([q+1])
     int* hand;                           // [V][nchunks+1][4]: what chunk q takes over from the chunk on its left for row r: {F carry
