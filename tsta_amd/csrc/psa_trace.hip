@@ -215,8 +215,9 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
 // One pair, one launch, four consecutive bands per workgroup: band 4b+j runs in wave j.  Inside the workgroup the bands are
 // linked through LDS rings (above); the first band of a workgroup takes its top row from memory and the last one leaves its
 // bottom row there, exactly as psa_trace_tile_kernel<.., PERSIST> does (sc1 stores, progress word, sc1 polls and loads).
-// Workgroups are assigned statically, so ALL of them must be resident: the host launches this kernel only when there are no
-// more workgroups than compute units; it then cannot deadlock (a band waits only for the band above).
+// A workgroup's four bands are a ticket drawn when it starts (HIP promises no dispatch order): the band a workgroup's first wave
+// waits for belongs to a workgroup that started earlier, so the waits end whatever the residency.  (The host still launches this
+// form only when there are no more workgroups than compute units: queued workgroups would only lengthen the chain.)
 template <int R>
 __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
 {
@@ -225,10 +226,12 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
     __shared__ int2 ring[3][kRing + 64];
     __shared__ int done[4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ int wg_s;
     if (threadIdx.x < 4) done[threadIdx.x] = 0;
+    if (threadIdx.x == 0) wg_s = (int)atomicAdd(A.ticket, 1u);
     __syncthreads();
     const TraceJob& J = A.jobs[0];
-    const int w = blockIdx.x * 4 + wave, g = J.band0 + w;
+    const int w = __builtin_amdgcn_readfirstlane(wg_s) * 4 + wave, g = J.band0 + w;
     if (w >= J.W) return;
     const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O, S_total = J.S_total;
     const uint8_t* __restrict__ seq_a = J.a;
