@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
             if (forced < 0) {
                 // ---- diagonal run: lane l probes cell (i-l, j-l); the run of leading "diag" cells is taken at once
                 const int ci = i - lane, cj = j - lane;
-                bool isdiag = false;
+                bool isdiag = false, seen = false;
                 int byte_l = 0;
                 if (ci >= 1 && cj >= 1) {
                     const int cw = (ci - 1) / BAND, rr = (ci - 1) % BAND, cl = rr / R, ck = rr % R;
@@ -556,6 +556,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                     if (cw == w && cq >= qlo) {
                         const size_t off = ((size_t)(cq - qlo) * 64 + cl) * 16 + (ct % SPB) * R + ck;
                         byte_l = wb[off];
+                        seen = true;
                         isdiag = !(byte_l & 1u);                  // psa.c:443: back == 1
                     }
                 }
@@ -564,9 +565,11 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                 if (run > 0) {
                     if (lane < run) *(GlobalU8*)(A.ops + cnt + lane) = 1;
                     i -= run; j -= run; cnt += run;
-                    continue;
-                }
-                c = (unsigned)__builtin_amdgcn_readfirstlane(byte_l);     // lane 0 probed (i, j) itself (inside the window)
+                    // the cell that ended the run was probed too (lane `run`): its step follows without another probe
+                    if (run == 64 || i < 1 || j < 1 || !((__ballot(seen) >> run) & 1ull)) continue;
+                    c = (unsigned)__builtin_amdgcn_readlane(byte_l, run);
+                } else
+                    c = (unsigned)__builtin_amdgcn_readfirstlane(byte_l); // lane 0 probed (i, j) itself (inside the window)
             }
             // ---- one non-diagonal (or forced) step, computed identically by every lane (a forced step does not look at its cell)
             int k;
