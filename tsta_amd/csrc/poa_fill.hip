@@ -471,35 +471,73 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     int num2 = A.n - 1, forced = -1, ns = 0;
     if (lane == 0) A.out[2] = num1;
     bool pend = false; int pend_node = 0, pend_col = 0, pend_code = 0, pend_idx = 0;     // LINKS: diagonal step waiting for its peek
+    bool try_probe = true;                                     // LINKS: the walk is in a stretch of backbone cells (distance-1 links)
     LdsI8* wb = (LdsI8*)reinterpret_cast<const int8_t*>(win);
 
-    while (num1 != -1 && num2 != -1) {
-        // stage the window whose lower-right region holds (num1, num2)
-        const int rw0 = max(0, num1 - (kWalkRows - 1)), cw0 = max(0, (num2 - 48) & ~15);
+    // A window in registers: what one lane holds of it (rows lane and 64 + lane), and how it is loaded / put into LDS.  The
+    // window the walk will need NEXT is loaded while the current one is walked (`nxt`): a walk runs out of columns first (64
+    // per window), about as many rows further up.
+    struct WinRegs { uint4 t[kWalkRows / 64][3][4]; int po[kWalkRows / 64], po1[kWalkRows / 64]; int4 pr[kWalkRows / 64]; };   // (nothing derived: no wait at load time)
+    typedef unsigned int u32x4_w __attribute__((ext_vector_type(4)));
+    auto load_window = [&](WinRegs& W, int rw0, int cw0) {
 #pragma unroll
         for (int h = 0; h < kWalkRows / 64; ++h) {
-            const int wr = h * 64 + lane, rr = rw0 + wr;
-            uint4 t[3][4];
-            int po = 0, np_ = 0;
-            int4 pr = make_int4(-1, -1, -1, -1);
-            if (rr < A.V) { po = A.pred_off[rr]; np_ = A.pred_off[rr + 1] - po; pr = A.ptab[rr]; }
+            const int rr = rw0 + h * 64 + lane;
+            W.po[h] = 0; W.po1[h] = 0; W.pr[h] = make_int4(-1, -1, -1, -1);
+            if (rr < A.V) { W.po[h] = A.pred_off[rr]; W.po1[h] = A.pred_off[rr + 1]; W.pr[h] = A.ptab[rr]; }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int64_t col = cw0 + 16 * x;
-                    t[a][x] = (rr < A.V && col < A.tpitch) ? *reinterpret_cast<const uint4*>(base + (size_t)rr * A.tpitch + col)
-                                                            : make_uint4(0, 0, 0, 0);
+                    W.t[h][a][x] = make_uint4(0, 0, 0, 0);
+                    if (rr < A.V && col < A.tpitch) {
+                        const u32x4_w v = *(__attribute__((address_space(1))) const u32x4_w*)(base + (size_t)rr * A.tpitch + col);
+                        W.t[h][a][x] = make_uint4(v.x, v.y, v.z, v.w);
+                    }
                 }
             }
+        }
+    };
+    auto store_window = [&](const WinRegs& W, int rw0) {
+#pragma unroll
+        for (int h = 0; h < kWalkRows / 64; ++h) {
+            const int wr = h * 64 + lane, rr = rw0 + wr;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) win[a][wr][x] = t[a][x];
-            wpo[wr] = po; wnp[wr] = np_;
+                for (int x = 0; x < 4; ++x) win[a][wr][x] = W.t[h][a][x];
+            const int4 pr = W.pr[h];
+            wpo[wr] = W.po[h]; wnp[wr] = W.po1[h] - W.po[h];
             wpred[wr][0] = pr.x; wpred[wr][1] = pr.y; wpred[wr][2] = pr.z; wpred[wr][3] = pr.w;
             wbb[wr] = (rr >= 1) ? ((pr.x == rr - 1 ? 1 : 0) | (pr.y == rr - 1 ? 2 : 0) | (pr.z == rr - 1 ? 4 : 0) | (pr.w == rr - 1 ? 8 : 0)) : 0;
+        }
+    };
+    WinRegs nxt;
+    int nxt_rw0 = -1, nxt_cw0 = -1;
+
+    while (num1 != -1 && num2 != -1) {
+        // stage the window whose lower-right region holds (num1, num2): the predicted one if the walk arrived inside it with room
+        // to go on, else a fresh one
+        int rw0, cw0;
+        if (nxt_rw0 >= 0 && num1 >= nxt_rw0 + 32 && num1 < nxt_rw0 + kWalkRows && num2 >= nxt_cw0 + 16 && num2 < nxt_cw0 + 64) {
+            rw0 = nxt_rw0; cw0 = nxt_cw0;
+            store_window(nxt, rw0);
+        } else {
+            rw0 = max(0, num1 - (kWalkRows - 1)); cw0 = max(0, (num2 - 48) & ~15);
+            WinRegs cur;
+            load_window(cur, rw0, cw0);
+            store_window(cur, rw0);
+        }
+        nxt_rw0 = -1;
+        if (cw0 > 0) {
+            // the walk leaves this window on its left, at column cw0 - 1, at least one row further up per column on the way
+            const int c1 = cw0 - 1, r1 = num1 - (num2 - cw0 + 1);
+            if (r1 >= 0) {
+                nxt_rw0 = max(0, r1 - (kWalkRows - 1)); nxt_cw0 = max(0, (c1 - 48) & ~15);
+                load_window(nxt, nxt_rw0, nxt_cw0);
+            }
         }
         __syncthreads();
         // one trace byte of array a at a wave-uniform (row, col): from the window (the same LDS address in every lane) or,
@@ -519,11 +557,45 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             int wi = num1 - rw0, wc = num2 - cw0;
             if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
             if constexpr (LINKS) {
+                if (forced < 0 && try_probe) {
+                    // ---- a run of backbone cells (diagonal moves to the row just above: link distance 1) is taken at once: lane l
+                    // probes cell (num1 - l, num2 - l), as the walker of the K4 path does with its predecessor bits.  Worth it only
+                    // in such stretches: a short run switches the probe off, the loop below switches it on again.
+                    const int x = wi - lane, y = wc - lane;
+                    const bool have = x >= 0 && y >= 0;
+                    int sb_l = 0, fb_l = 0;
+                    if (have) { sb_l = wb[x * 64 + y]; fb_l = wb[(2 * kWalkRows + x) * 64 + y]; }
+                    const bool okc = have && (unsigned)(sb_l - 42) < 84u && ((fb_l >> 3) & 31) == 1 &&
+                                     ((x >= 1 && y >= 1 && lane < 63) || num2 - lane == 0);
+                    const unsigned long long mask = __ballot(okc);
+                    const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
+                    if (run < 4) try_probe = false;
+                    if (run >= 2) {
+                        if (pend) {                                // the step before was a diagonal move to lane 0's cell
+                            const int sb0 = __builtin_amdgcn_readfirstlane(sb_l);
+                            if (lane == 0) {
+                                tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code;
+                                st.peek = (int8_t)(((unsigned)(sb0 - 42) < 42u) ? 1 : 0); st.pad = 0;
+                                A.steps[pend_idx] = st;
+                            }
+                            pend = false;
+                        }
+                        const int nxt_sb = __builtin_amdgcn_update_dpp(0, sb_l, 0x130, 0xf, 0xf, false);      // lane l+1's (wave_shl:1)
+                        if (lane < run) {
+                            const int c = num2 - lane;
+                            tsta_poa_step st; st.node = num1 - lane; st.col = c; st.code = (int8_t)sb_l;
+                            st.peek = (int8_t)((c > 0 && (unsigned)(nxt_sb - 42) < 42u) ? 1 : 0); st.pad = 0;
+                            A.steps[ns + lane] = st;
+                        }
+                        ns += run; num1 -= run; num2 -= run;
+                        continue;
+                    }
+                }
                 if (forced < 0) {
                     // ---- consecutive diagonal steps inside the window: the steps are collected in lanes (v_writelane) and stored
                     // 64 at a time; a step's peek is known one step later, so its code word is written then
                     int bufN = 0, bufC = 0, bufW = 0;
-                    int k = 0, base_idx = ns, prev_code = 0;
+                    int k = 0, base_idx = ns, prev_code = 0, ones = 0;
                     if (pend) { wlane(bufN, pend_node, 0); wlane(bufC, pend_col, 0); prev_code = pend_code; base_idx = pend_idx; k = 1; pend = false; }
                     int a = wi * 64 + wc;                        // byte of the cell in the window's source array
                     int why;                                     // 0: the cell is not a linked diagonal move, 1: left the window / buffer full, 2: the walk is over
@@ -535,8 +607,10 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                         if ((unsigned)(sb - 42) >= 84u || d == 0) { why = 0; break; }
                         wlane(bufN, num1, k); wlane(bufC, num2, k); prev_code = sb; ++k; ++ns;
                         num1 -= d; num2 -= 1; a -= d * 64 + 1;
+                        ones = (d == 1) ? ones + 1 : 0;
                         if (num2 < 0) { wlane(bufW, prev_code, k - 1); why = 2; break; }            // (no next cell: peek 0)
-                        if (num1 < rw0 || num2 < cw0 || k == 64) { why = 1; break; }
+                        if (ones >= 8) try_probe = true;                                            // a backbone stretch: probe it
+                        if (num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8) { why = 1; break; }
                     }
                     // entries 0 .. k-1 are complete, except the last one when the loop stopped for the window / the buffer
                     int done = k;
