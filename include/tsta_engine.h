@@ -5,8 +5,12 @@
  * through three `main()`s and a `void block_alignment(void* pack)` thread-pool task that communicates
  * through process globals (psa/psa.c:113-137,365-433; msa/c-t-simd.c:26-34,602-657).  Each entry point
  * below replaces one such region of the reference; the citation says which.  Plain C, plain pointers and
- * sizes; no HIP, C++ or torch types.  Every function returns 0 (TSTA_OK) or a negative tsta_status and
- * never calls exit() (the reference exit()s / crashes on errors, seqio.c:38,47,180; c-t-simd.c:154).
+ * sizes; no HIP, C++ or torch types.  Every function returns a tsta_status and never calls exit() (the reference
+ * exit()s / crashes on errors, seqio.c:38,47,180; c-t-simd.c:154).
+ *
+ * STATUS CONVENTION: rc < 0 is a failure (outputs invalid), rc == 0 success, rc > 0 success WITH A WARNING (outputs valid;
+ * today only TSTA_WARN_REFERENCE_UNDEFINED from tsta_poa_fill / tsta_poa_align, e.g. for any sequence containing 'N').
+ * Test with TSTA_FAILED(rc), never with rc != TSTA_OK.
  *
  * Threading: one engine per host thread / per GPU.  An engine owns its device workspaces.
  */
@@ -31,6 +35,9 @@ typedef enum tsta_status {
     TSTA_ERR_UNSUPPORTED = -5,    /* input outside the supported domain (documented per function) */
     TSTA_ERR_INTERNAL = -6
 } tsta_status;
+
+#define TSTA_FAILED(rc)    ((rc) < 0)     /* failure: outputs invalid */
+#define TSTA_SUCCEEDED(rc) ((rc) >= 0)    /* success, possibly with a TSTA_WARN_* (rc > 0) */
 
 /* Scoring parameters = the reference's globals M, X, E, O (psa.c:114-117, msa.c:22-25).
  * A gap of length k costs O + k*E. */
@@ -80,6 +87,9 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
  *                      waits all the same, the call is run again through the other form | 0: always one launch per tile
  *                      anti-diagonal | 2: as 1, and every call is treated as abandoned once (tests of that second run)
+ *   "test_abandon"     0 (default) | t >= 1: in every single-launch form the holder of ticket t-1 computes its work but never
+ *                      publishes it, so that its dependants run into their bounded waits (tests of the second run; see
+ *                      tsta_psa_score_batch_dev_status)
  *   "poa_ref_block"    L = block * W of the reference build whose behaviour TSTA_WARN_REFERENCE_UNDEFINED is judged against
  *                      (default 640 = AVX512 x -W 10; the TSTA_msa drop-in passes 64 x its -W); multiple of 16, 16 .. 1048576
  * Returns TSTA_ERR_INVALID_ARG for an unknown key or value. */
@@ -107,6 +117,20 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
 int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs,
                              const int64_t* d_off1, const int32_t* d_len1, const int64_t* d_off2,
                              const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream);
+
+/* Single-launch forms and what happens when one gives up.  Several fills run as ONE launch whose waves hand rows to each
+ * other through memory inside the launch (K1b band pipeline of small score batches, the trace fills, the POA dataflow fill).
+ * Work is handed out as tickets in dependency order, so a wave only ever waits for one that is already running; the waits are
+ * bounded all the same, and a wave whose wait does not end (a chip shared with other kernels) sets a status word and the
+ * launch drains.  EVERY entry point then behaves the same way: the host-pointer forms (tsta_psa_score_batch[_2bit|_multi],
+ * tsta_psa_align[_batch], tsta_poa_fill, tsta_poa_align) notice it and run the call again, in the same process, through the
+ * launch-per-diagonal form of the same kernels (tsta_engine_stat "single_launch_reruns" counts these); the asynchronous
+ * device-pointer forms cannot, so there every score of the call is poisoned — out[k] = INT32_MIN, a value no alignment has —
+ * and tsta_psa_score_batch_dev_status() (synchronises `stream`) returns TSTA_ERR_INTERNAL.  No path returns success with a
+ * wrong number.  Option "test_abandon" forces the event in tests. */
+int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
+/* Counters of an engine: "single_launch_reruns".  TSTA_ERR_INVALID_ARG for an unknown key. */
+int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);
 
 /* 2-bit packed input for pure-ACGT batches: a quarter of the host memory, PCIe traffic and input
  * HBM of the byte form.  Every sequence starts on a byte boundary of `packed`; 4 bases per byte, base i of a sequence in

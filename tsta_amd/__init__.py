@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "tsta_pack_2bit", "tsta_psa_score_batch_2bit", "tsta_psa_score_batch_dev_2bit", "tsta_engine_release_workspaces",
     "tsta_multi_create", "tsta_multi_destroy", "tsta_multi_device_count", "tsta_multi_engine", "tsta_multi_last_error",
     "tsta_multi_set_option", "tsta_shard_bounds", "tsta_psa_score_batch_multi", "tsta_psa_align_batch_multi",
-    "tsta_build_info", "tsta_device_uuid", "tsta_last_warning",
+    "tsta_build_info", "tsta_device_uuid", "tsta_last_warning", "tsta_psa_score_batch_dev_status", "tsta_engine_stat",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
         L.tsta_poa_align.restype = C.c_int
         L.tsta_poa_align.argtypes = [vp, C.POINTER(Params), C.POINTER(DagCsr), vp, i32, C.POINTER(vp), C.POINTER(i64),
                                      C.POINTER(i32), vp]
+        L.tsta_psa_score_batch_dev_status.restype = C.c_int; L.tsta_psa_score_batch_dev_status.argtypes = [vp, vp]
+        L.tsta_engine_stat.restype = C.c_int; L.tsta_engine_stat.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
         L.tsta_last_kernel_ms.restype = C.c_int
         L.tsta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
         L.tsta_build_info.restype = C.c_char_p; L.tsta_build_info.argtypes = []
@@ -328,6 +330,16 @@ class Engine:
         rc = lib().tsta_psa_score_batch_dev(self._h, C.byref(params), int(n_pairs), d_seqs, d_off1, d_len1, d_off2,
                                             d_len2, d_out, int(max_len), C.c_void_p(stream or None))
         self._check(rc, "tsta_psa_score_batch_dev")
+
+    def psa_score_batch_dev_status(self, stream=0):
+        """Synchronises `stream`; raises if the last psa_score_batch_dev's single-launch band pipeline abandoned a wait
+        (its scores are then INT32_MIN).  See tsta_psa_score_batch_dev_status in include/tsta_engine.h."""
+        self._check(lib().tsta_psa_score_batch_dev_status(self._h, C.c_void_p(stream or None)), "tsta_psa_score_batch_dev_status")
+
+    def stat(self, key):
+        v = C.c_int64()
+        self._check(lib().tsta_engine_stat(self._h, key.encode(), C.byref(v)), "tsta_engine_stat(%s)" % key)
+        return int(v.value)
 
     # ---- PSA with traceback (TSTA_psa) --------------------------------------------------------------
     def psa_align(self, s1, s2, params=None):

@@ -228,9 +228,32 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
     if (!strcmp(key, "trace_lds") && (v == 0 || v == 1)) { e->opt_trace_lds = v; return TSTA_OK; }
     if (!strcmp(key, "poa_dataflow") && (v == 0 || v == 1 || v == 2)) { e->opt_poa_dataflow = v; return TSTA_OK; }
+    if (!strcmp(key, "test_abandon") && v >= 0) { e->opt_test_abandon = v; return TSTA_OK; }
     if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;
+}
+
+int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
+{
+    if (!eng || !key || !value) return TSTA_ERR_INVALID_ARG;
+    const Engine* e = reinterpret_cast<const Engine*>(eng);
+    if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
+    return TSTA_ERR_INVALID_ARG;
+}
+
+int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream)
+{
+    if (!eng) return TSTA_ERR_INVALID_ARG;
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
+    if (rc != TSTA_OK) return rc;
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+    unsigned st = 0;
+    if (e->psa_status && (rc = e->check(hipMemcpyAsync(&st, e->psa_status, sizeof(st), hipMemcpyDeviceToHost, s), "D2H band pipeline status"))) return rc;
+    if ((rc = e->check(hipStreamSynchronize(s), "hipStreamSynchronize"))) return rc;
+    if (st) { e->set_error("single-launch band pipeline abandoned a wait (status %u): the scores of that call are INT32_MIN", st); return TSTA_ERR_INTERNAL; }
+    return TSTA_OK;
 }
 
 int tsta_last_kernel_ms(tsta_engine* eng, float* ms, int32_t* n_launches)

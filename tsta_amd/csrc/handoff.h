@@ -7,7 +7,11 @@
 // No agent-scope fence on either side: no L2 write-back, no L1/L2 invalidate.  All accesses are global_* (the pointers are
 // cast to the global address space: the compiler would otherwise emit flat_*, which the guide excludes).
 // Deadlock freedom is the callers' business (bands are handed out as tickets in dependency order); a poll that does not
-// end sets a status bit and gives up, so that every wave terminates and the host reports the failure.
+// end sets a status bit and gives up, so that every wave terminates; the word is read by the finishing kernel of every such
+// launch (results are poisoned, never silently wrong) and by the host entry points, which run the call again through the
+// launch-per-diagonal form of the same kernels.  Test hook shared by all single-launch families: engine option
+// "test_abandon" = t makes the wave (workgroup) that draws ticket t-1 do its work but never publish it, so that its
+// dependants really run into the bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,14 +59,19 @@ __device__ __forceinline__ void wait_progress(const int* word, int need, unsigne
         else __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 17)) { if (lane == 0) atomicOr(status, 1u); break; }      // far: ~14 s; near: ~0.1 s
         // once any wave has given up, nobody waits any more: the launch drains quickly
-        if ((spins & 255) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if ((spins & 15) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }
+    // compiler-only barrier: the sc1 loads of the entries that follow (other addresses, relaxed) must not be hoisted above
+    // the final poll.  The hardware ordering comes from the s_waitcnt on the poll's result, which the loop exit depends on.
+    asm volatile("" ::: "memory");
 }
 
 // one look at the word, no waiting (wave-uniform answer)
 __device__ __forceinline__ bool progress_reached(const int* word, int need)
 {
-    return __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= need;
+    const bool ok = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= need;
+    asm volatile("" ::: "memory");                              // (as at the end of wait_progress)
+    return ok;
 }
 
 // this wave's boundary-row stores have left; publish how far it is

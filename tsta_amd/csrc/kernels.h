@@ -81,6 +81,7 @@ struct PsaBandsArgs {
     // tile_wlo[d] .. tile_wlo[d] + tile_nw[d] - 1 of every couple; progress[couple * W_max + band] = steps published
     unsigned* ticket; int* progress; unsigned* status;
     const int* tile_first; const int* tile_wlo; const int* tile_nw; int n_d, n_tiles;
+    int test_abandon;               // test hook (handoff.h): the wave that draws ticket test_abandon-1 never publishes its tile; 0 = off
 };
 void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream);
 void launch_psa_score_bands_persistent(int R, const PsaBandsArgs& args, int n_cu, hipStream_t stream);

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
     if (threadIdx.x == 0) ticket_s = (int)atomicAdd(P.ticket, 1u);
     __syncthreads();
     const int q = __builtin_amdgcn_readfirstlane(ticket_s) - 1;      // this workgroup's chunk; -1: the column-0 solver below
+    const bool mute = P.test_abandon != 0 && q + 1 == P.test_abandon - 1 && q >= 0;   // test hook: this chunk never publishes a block
     if (q < 0) {
         // ================================================================ column 0 (c-t-simd.c:174-188, 194-200)
         // H(r, 0) = max over predecessors H(p, 0) + E (a source: O + E) depends on the graph only.  One wave walks the nodes
@@ -270,6 +271,9 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             const int (&pr)[4] = m.pr; const int (&ps)[4] = m.ps;
             if (rb >= 2 && !lds_wait_gt(&taken, rb - 2, P.status, lane)) break;     // the solver has copied block rb-2 out of this slot
             wait_progress(P.prog + q, rb + 1, P.status, lane);
+            // a launch in which any wait was abandoned stops here: nothing more is staged, the solver and the emitters run
+            // into their own (bounded) waits and return; the entry point runs the call again through K4
+            if (__hip_atomic_load((const GlobalU32*)P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             int xin = 0, flag = 1, edge = 0;
             if (lane < count) {
                 const int* hd = P.hand + ((size_t)(r0 + lane) * ncar + q) * 4;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
 
         if (wave == 0) {
             // ================================================================ solver
-            lds_wait_gt(&fetched, rb, P.status, lane);
+            if (!lds_wait_gt(&fetched, rb, P.status, lane)) return;      // (abandoned launch: fbuf was never staged)
             int poff_l, np_l, base_l, xin_l, flag_l, edge_l, pr_l[4], ps_l[4];
             {
                 const int (*fb)[kDfRB] = fbuf[rb & 1];
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
                                                           (np_l < 2 || pr_l[1] >= ring_lo) && (np_l < 3 || pr_l[2] >= ring_lo) && (np_l < 4 || pr_l[3] >= ring_lo));
             // blocks rb-3 and rb-2 are complete (all four waves, stores drained): the ring third of block rb-3 may be overwritten
             // (nobody reads it any more), and every row older than the ring can be read back from the H / Eagg rows
-            if (rb >= 2) lds_wait_gt(&blk_pub, rb - 2, P.status, lane);
+            if (rb >= 2 && !lds_wait_gt(&blk_pub, rb - 2, P.status, lane)) return;
             // per-row side data of the block's records, one row per lane
             if (lane < kDfRB) {
                 const int sl = s0 + lane;
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             const int em = (wave == 5) ? 3 : wave - 1;        // emitter number: rows em, em + 4, ...
             int seen = 0;
             const bool live = (em >= nrows) || lds_wait_gt_seen(&produced[lane], rows_base + em, seen, P.status, lane);
+            if (!live) return;                                // (abandoned launch)
             const int sl_b = s0 + (lane & (kDfRB - 1));
             const int edge_b = side[S_EDGE][sl_b], flag_b = side[S_FLAG][sl_b], np_b = side[S_NP][sl_b], poff_b = side[S_POFF][sl_b];
             const int pr_b[4] = {side[S_PR0][sl_b], side[S_PR1][sl_b], side[S_PR2][sl_b], side[S_PR3][sl_b]};
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             const unsigned long long near_mask = __ballot(lane < nrows && np_b >= 1 && np_b <= 4 && pr_b[0] >= ring_lo && (np_b < 2 || pr_b[1] >= ring_lo) &&
                                                           (np_b < 3 || pr_b[2] >= ring_lo) && (np_b < 4 || pr_b[3] >= ring_lo));
             for (int i = em; live && i < nrows; i += kDfEmit) {
-                if (!lds_wait_gt_seen(&produced[lane], rows_base + i, seen, P.status, lane)) break;
+                if (!lds_wait_gt_seen(&produced[lane], rows_base + i, seen, P.status, lane)) return;
                 const int r = r0 + i, si = s0 + i;
                 const int hs0 = rec[si][F_HS0][lane], hs1 = rec[si][F_HS1][lane], es0 = rec[si][F_ES0][lane], es1 = rec[si][F_ES1][lane];
                 const int fl0 = rec[si][F_FL0][lane], fl1 = rec[si][F_FL1][lane];
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             const int before = __hip_atomic_fetch_add(&blk_done[rb & 3], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (before == kDfEmit) {
                 __hip_atomic_store(&blk_done[rb & 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store((GlobalI32*)(P.prog + q + 1), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!mute) __hip_atomic_store((GlobalI32*)(P.prog + q + 1), rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&blk_pub, rb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -629,6 +634,7 @@ int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_in
     P.A = A;
     P.ticket = reinterpret_cast<unsigned*>(d_work); P.status = reinterpret_cast<unsigned*>(d_work + 1); P.prog = d_work + 16;
     P.hand = d_hand;
+    P.test_abandon = e->opt_test_abandon;
     hipLaunchKernelGGL(poa_dataflow_kernel, dim3(A.nchunks + 1), dim3(kDfThreads), 0, s, P);
     return e->check(hipGetLastError(), "poa dataflow launch");
 }

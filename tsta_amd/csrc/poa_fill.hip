@@ -435,7 +435,8 @@ struct PoaWalkArgs {
     const int8_t* source; const int8_t* esource; const int8_t* fsource; int64_t tpitch;
     const int* lastscore;
     tsta_poa_step* steps;                // out, capacity V + n + 2
-    int* out;                            // out[0] = number of steps, out[1] = end column, out[2] = start node
+    int* out;                            // out[0] = number of steps (-1: the walk was refused / ran into inconsistent trace arrays), out[1] = end column, out[2] = start node
+    const unsigned* status;              // status word of the single-launch fill before it (null: none): non-zero = the arrays are not to be trusted
 };
 
 constexpr int kWalkRows = 128;           // rows of the walker's window (the graph has ~2 nodes per column: rows run out first)
@@ -458,6 +459,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     __shared__ int wpo[kWalkRows], wnp[kWalkRows], wpred[kWalkRows][4];   // predecessor lists of the window's rows (first 4 of each)
     __shared__ int wbb[kWalkRows];       // bit j: predecessor j of the row is the row just above it
     const int lane = threadIdx.x;
+    // Guards (the arrays may come from a single-launch fill that abandoned its waits: garbage): refuse to start when the
+    // fill's status word is set; on the way, every step must move to a smaller node or a smaller column and every code must
+    // be one the fill can have written — then ns <= V + n (the capacity of steps[]) and every read stays inside the arrays.
+    // A violation ends the walk with out[0] = -1.
+    if (A.status != nullptr && __builtin_amdgcn_readfirstlane((int)*A.status) != 0) { if (lane == 0) { A.out[0] = -1; A.out[1] = A.n - 1; } return; }
+    bool bad = false;
     // start: best sink among sort indices >= 1 (max lastsorce, lowest index on ties), else the last node (:737-750)
     int bv = INT_MIN, bi = -1;
     for (int i = 1 + lane; i < A.V; i += 64)
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     WinRegs nxt;
     int nxt_rw0 = -1, nxt_cw0 = -1;
 
-    while (num1 != -1 && num2 != -1) {
+    while (num1 >= 0 && num2 >= 0) {
         // stage the window whose lower-right region holds (num1, num2): the predicted one if the walk arrived inside it with room
         // to go on, else a fresh one
         int rw0, cw0;
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             return __builtin_amdgcn_readfirstlane(v);
         };
         for (;;) {
-            if (num1 == -1 || num2 == -1) break;
+            if (num1 < 0 || num2 < 0) break;
             int wi = num1 - rw0, wc = num2 - cw0;
             if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
             if constexpr (LINKS) {
@@ -639,6 +646,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 const bool was_forced = forced >= 0;
                 const int code = was_forced ? forced : sb;
                 forced = -1;
+                if (code < 0) { bad = true; num1 = -1; break; }
                 const int kind = code / 42, pidx = code % 42;
                 int Psub = -1;
                 const int d = (fb >> 3) & 31;
@@ -651,6 +659,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                             else Psub = __builtin_amdgcn_readfirstlane(A.pred[__builtin_amdgcn_readfirstlane(wpo[wi]) + pidx]);
                         }
                     }
+                    if (Psub < -1 || Psub >= num1) { bad = true; num1 = -1; break; }
                 }
                 int n1 = num1, n2 = num2;
                 bool defer = false;
@@ -709,6 +718,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 }
                 code = __builtin_amdgcn_readfirstlane(code_l);                // lane 0 probed (num1, num2) itself
             } else { code = forced; forced = -1; }
+            if (code < 0) { bad = true; num1 = -1; break; }
             const int kind = code / 42, pidx = code % 42;
             const int np = __builtin_amdgcn_readfirstlane(wnp[wi]);
             int Psub = -1;
@@ -716,6 +726,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 if (pidx < 4) Psub = __builtin_amdgcn_readfirstlane(wpred[wi][pidx]);
                 else Psub = __builtin_amdgcn_readfirstlane(A.pred[__builtin_amdgcn_readfirstlane(wpo[wi]) + pidx]);
             }
+            if (Psub < -1 || Psub >= num1) { bad = true; num1 = -1; break; }
             int peek = 0;
             int n1 = num1, n2 = num2;
             if (kind == 3) {                                   // F (:753-772)
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code; st.peek = 0; st.pad = 0;
         A.steps[pend_idx] = st;
     }
-    if (lane == 0) { A.out[0] = ns; A.out[1] = num2; }
+    if (lane == 0) { A.out[0] = bad ? -1 : ns; A.out[1] = num2; }
 }
 
 }  // namespace tsta
@@ -987,6 +998,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     Wk.lastscore = A.lastscore;
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
     Wk.out = A.best + 4;
+    Wk.status = e->poa_status;                              // (dataflow fill: the walker does not start on arrays of an abandoned launch)
     if (A.links) hipLaunchKernelGGL(poa_walk_kernel<true>, dim3(1), dim3(64), 0, s, Wk);
     else hipLaunchKernelGGL(poa_walk_kernel<false>, dim3(1), dim3(64), 0, s, Wk);
     e->n_launches += 1;
@@ -1014,6 +1026,7 @@ template <class F> static int poa_with_fallback(tsta_engine* eng, F once)
     if (rc != tsta::kPoaDataflowGaveUp) return rc;
     tsta::Engine* e = reinterpret_cast<tsta::Engine*>(eng);
     const int keep = e->opt_poa_dataflow;
+    ++e->single_launch_reruns;
     e->opt_poa_dataflow = 0;
     rc = once();
     e->opt_poa_dataflow = keep;

@@ -46,6 +46,7 @@ struct PoaDfArgs {
     int* prog;                           // [nchunks+1]: blocks of 32 nodes completed by the column-0 solver ([0]) and by chunk q ([q+1])
     int* hand;                           // [V][nchunks+1][4]: what chunk q takes over from the chunk on its left for row r: {F carry
                                          // entering the chunk, "its first F is an open", H(r, column left of the chunk), unused} (sc1 hand-off)
+    int test_abandon;                    // test hook (handoff.h): the workgroup that draws ticket test_abandon-1 never publishes its blocks; 0 = off
 };
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s);
 

@@ -182,6 +182,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+    e->psa_status = nullptr;
 
     // ---- packed-int16 kernel (K1p) for couples of equal-geometry pairs, when the scoring fits 16-bit lanes
     // one wave nearly saturates a SIMD, so packing two pairs per wave only pays once there are more
@@ -251,7 +252,8 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
         const int64_t bblocks = (couples * ba.W_max + 3) / 4;
         if (bblocks > 0x7fffffffLL) return TSTA_ERR_UNSUPPORTED;
         ba.ticket = nullptr; ba.progress = nullptr; ba.status = nullptr; ba.tile_first = ba.tile_wlo = ba.tile_nw = nullptr; ba.n_d = 0; ba.n_tiles = 0;
-        bool dataflow = e->opt_trace_persistent != 0 && couples * ba.W_max <= (1 << 22) && D <= (1 << 20);
+        ba.test_abandon = e->opt_test_abandon;
+        bool dataflow = e->opt_trace_persistent != 0 && !e->no_single_launch && couples * ba.W_max <= (1 << 22) && D <= (1 << 20);
         std::vector<int>& tab = e->host_tab;
         if (dataflow) {
             if (e->ev_tab) (void)hipEventSynchronize(e->ev_tab);          // the previous call's upload of this vector has finished
@@ -288,6 +290,7 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
             ba.d = 0;
             tsta::launch_psa_score_bands_persistent(Rb, ba, e->n_cu, s);
             ++launches;
+            e->psa_status = ba.status;                          // read by the finish kernel (poison) and by the host forms (second run)
         } else
         for (int64_t d = 0; d < D; ++d) {
             ba.d = (int)d;
@@ -347,6 +350,23 @@ int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs
 }  // extern "C"
 
 namespace tsta {
+
+// After a *_dev call enqueued on the engine's stream by a host-pointer form: if its single-launch band pipeline (K1b)
+// abandoned a wait — the device scores are then poison, psa_score_bands_finish_kernel — the same call is enqueued again with
+// the single-launch forms off (launch-per-diagonal pipeline: the kernel boundary is the only synchronisation), as the trace
+// and POA entry points do (psa_trace.hip: run_group, poa_fill.hip: poa_with_fallback).  Synchronises the stream.
+template <class F> static int psa_score_rerun_if_abandoned(Engine* e, F again)
+{
+    if (!e->psa_status) return TSTA_OK;
+    unsigned st = 0;
+    int rc = e->copy_sync(&st, e->psa_status, sizeof(st), hipMemcpyDeviceToHost, "D2H band pipeline status");
+    if (rc != TSTA_OK || st == 0u) return rc;
+    ++e->single_launch_reruns;
+    e->no_single_launch = true;
+    rc = again();
+    e->no_single_launch = false;
+    return rc;
+}
 
 // tsta_psa_score_batch proper.  out (host) may be NULL when d_scores is given: the scores then stay on the device, in a
 // buffer of at least max(n_pairs, dev_count) int32 (tsta_psa_score_batch_multi gathers them with RCCL from there), and
@@ -416,6 +436,10 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
     rc = tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                   d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
+    if ((rc = psa_score_rerun_if_abandoned(e, [&] {
+            return tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+                                            d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s); })) != TSTA_OK)
+        return rc;
     if (out && (rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
     return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
 }
@@ -503,6 +527,10 @@ int tsta_psa_score_batch_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_
     rc = tsta_psa_score_batch_dev_2bit(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                        d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
+    if ((rc = tsta::psa_score_rerun_if_abandoned(e, [&] {
+            return tsta_psa_score_batch_dev_2bit(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+                                                 d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s); })) != TSTA_OK)
+        return rc;
     if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
     return e->check(hipStreamSynchronize(s), "psa_score_batch_2bit sync");
 }

@@ -158,6 +158,8 @@ __device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* statu
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 22)) { if (lane == 0) atomicOr(status, 4u); break; }
+        // once any wave of the launch has given up, nobody waits any more
+        if ((spins & 4095) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler ordering only: the LDS performs a wave's operations in issue order
 }
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
     const TraceJob& J = A.jobs[0];
     const int w = __builtin_amdgcn_readfirstlane(wg_s) * 4 + wave, g = J.band0 + w;
     if (w >= J.W) return;
+    const bool mute = A.test_abandon != 0 && __builtin_amdgcn_readfirstlane(wg_s) == A.test_abandon - 1;   // test hook: never publishes
     const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O, S_total = J.S_total;
     const uint8_t* __restrict__ seq_a = J.a;
     const uint8_t* __restrict__ seq_b = J.b;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
         if (!bot_lds) {
             const int cs = t0 - 64 + lane;
             if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
-            publish_progress(&A.progress[g], t0 + 64, lane);
+            if (!mute) publish_progress(&A.progress[g], t0 + 64, lane);
         }
     }
 #pragma unroll
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         g = A.g_lo + blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     }
     if (g >= A.g_hi) return;
+    const bool mute = PERSIST && A.test_abandon != 0 && g == A.test_abandon - 1;     // test hook: this band never publishes
     int lo = 0, hi = A.n_jobs - 1;              // job = last one whose first band is <= g
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.jobs[mid].band0 <= g) lo = mid; else hi = mid - 1; }
     const TraceJob& J = A.jobs[lo];
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void psa_trace_tile_kernel(PsaTraceArgs A)
         const int cs = t0 - 64 + lane;
         if (PERSIST) {
             if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
-            publish_progress(&A.progress[g], t0 + 64, lane);
+            if (!mute) publish_progress(&A.progress[g], t0 + 64, lane);
         } else {
             if (cs >= 0 && cs < n) bot[cs] = make_int2(s.sh, s.se);
         }
@@ -655,8 +659,10 @@ static bool packed_trace_fits(const tsta_params& p)
 // All jobs of the group are in flight together: launch d advances every band of every job by one T-step tile.
 // With R = kPackedTraceR and a scoring that fits 16-bit lanes, jobs of similar geometry are coupled and filled two per
 // wave by K2p (psa_trace_packed.hip); the rest ("singles") by K2.
+// single_launch = false: every fill through the launch-per-diagonal pipeline (what a call is run again with after a single
+// launch abandoned a wait).
 template <int R, bool TRACE>
-static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs, int T)
+static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs, int T, bool single_launch = true)
 {
     constexpr int NSP = packed_state_ints(kPackedTraceR);
     hipStream_t s = e->stream;
@@ -722,8 +728,8 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     int* d_sync = reinterpret_cast<int*>(reinterpret_cast<char*>(d_out) + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256);
     // one pair per wave: a wave owns a band from its first step to its last (psa_trace_tile_kernel<.., PERSIST>) — right for the
     // single-pair calls, whose bands are few and all on the critical path; many unpaired jobs keep the launch pipeline
-    const bool persistent = n_singles == 1 && e->opt_trace_persistent != 0;
-    const bool persistent_couples = n_couples > 0 && e->opt_trace_persistent != 0;
+    const bool persistent = n_singles == 1 && e->opt_trace_persistent != 0 && single_launch;
+    const bool persistent_couples = n_couples > 0 && e->opt_trace_persistent != 0 && single_launch;
     int sband0 = 0, cband0 = 0, max_n = 0;
     std::vector<TraceJob> singles;
     std::vector<uint8_t> h_seq(seq_b);
@@ -766,6 +772,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     PsaTraceArgs A;
     A.jobs = d_singles; A.n_jobs = n_singles; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.ticket = reinterpret_cast<unsigned*>(d_sync); A.status = reinterpret_cast<unsigned*>(d_sync + 1); A.progress = d_sync + 64;
+    A.test_abandon = e->opt_test_abandon;
     if ((persistent || persistent_couples) &&
         (rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int), s), "hipMemsetAsync(sync)")))
         return rc;
@@ -781,7 +788,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     // their own stream, so that the launch sequences overlap (one sequence's launch gaps and half-empty tails are
     // filled by the others' waves).  Chunk 0 rides on the engine's stream.
     B.ticket = reinterpret_cast<unsigned*>(d_sync + 2); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.progress = d_sync + 64 + single_bands;
-    B.tile_first = nullptr; B.tile_glo = nullptr; B.n_d = 0; B.n_tiles = 0;
+    B.tile_first = nullptr; B.tile_glo = nullptr; B.n_d = 0; B.n_tiles = 0; B.test_abandon = e->opt_test_abandon;
     int n_chunks = (n_couples >= 8 && e->opt_trace_streams != 1 && !persistent_couples) ? 4 : 1;
     for (int g = 0; g + 1 < n_chunks; ++g) {
         if (!e->side[g] && hipStreamCreateWithFlags(&e->side[g], hipStreamNonBlocking) != hipSuccess) { n_chunks = 1; break; }
@@ -910,7 +917,13 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     if (persistent || persistent_couples) {
         unsigned st = 0;
         if ((rc = e->copy_sync(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost, "D2H status"))) return rc;
-        if (st) { e->set_error("persistent trace fill: a band waited too long for the band above (status %u)", st); return TSTA_ERR_INTERNAL; }
+        if (st) {
+            // a wait was abandoned (the chip shared with other work, or the test hook): everything this launch left is
+            // suspect.  Same behaviour as the other single-launch families (psa_api.hip, poa_fill.hip): the call is run
+            // again, now, through the launch-per-diagonal pipeline — same kernels, the kernel boundary as only synchronisation.
+            ++e->single_launch_reruns;
+            return run_group<R, TRACE>(e, p, jobs, n_jobs, T, false);
+        }
     }
     // the walkers' ops: per-job copies for a few long alignments, one copy of the whole region for many short ones
     std::vector<uint8_t> h_ops;

@@ -368,11 +368,13 @@ __global__ __launch_bounds__(256, 4) void psa_trace_packed_tile_kernel(PsaTraceP
     const int lane = threadIdx.x & 63;
     for (;;) {
     int g, d = A.d;
+    bool mute = false;                          // test hook: this tile is computed but never published
     if (PERSIST) {
         unsigned ticket = 0;
         if (lane == 0) ticket = atomicAdd(A.ticket, 1u);
         const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
         if (t >= A.n_tiles) return;
+        mute = A.test_abandon != 0 && t == A.test_abandon - 1;
         int lo = 0, hi = A.n_d - 1;             // d = last one whose first tile is <= t
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.tile_first[mid] <= t) lo = mid; else hi = mid - 1; }
         d = lo;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256, 4) void psa_trace_packed_tile_kernel(PsaTraceP
     if (C.perm) packed_tile<R, true, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
     else        packed_tile<R, true, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, A.pe, A.po, A.pm, A.pmx, A.elide != 0);
     if (!PERSIST) return;
-    publish_progress(A.progress + g, s1, lane);
+    if (!mute) publish_progress(A.progress + g, s1, lane);
     }
 }
 
@@ -454,11 +456,13 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     const int lane = threadIdx.x & 63;
     for (;;) {
     int64_t c; int w, d = P.d;
+    bool mute = false;                          // test hook: this tile is computed but never published
     if (PERSIST) {
         unsigned ticket = 0;
         if (lane == 0) ticket = atomicAdd(P.ticket, 1u);
         const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
         if (t >= P.n_tiles) return;
+        mute = P.test_abandon != 0 && t == P.test_abandon - 1;
         int lo = 0, hi = P.n_d - 1;             // d = last one whose first tile is <= t
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P.tile_first[mid] <= t) lo = mid; else hi = mid - 1; }
         d = lo;
@@ -506,11 +510,13 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
     else if (perm)       packed_tile<R, false, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
     else                 packed_tile<R, false, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
     if (!PERSIST) return;
-    publish_progress(prog, s1, lane);
+    if (!mute) publish_progress(prog, s1, lane);
     }
 }
 
-// per couple (blockIdx.x): out[pair] = max over the bands' lanes, floored at -100 (psa.c:110,590)
+// per couple (blockIdx.x): out[pair] = max over the bands' lanes, floored at -100 (psa.c:110,590).  After a single launch
+// that abandoned a wait (P.status set) every score of the call is poison (INT32_MIN): never a silently wrong answer; the
+// host-pointer entry points then run the call again through the launch pipeline (psa_api.hip).
 template <int R>
 __global__ void psa_score_bands_finish_kernel(PsaBandsArgs P)
 {
@@ -535,7 +541,8 @@ __global__ void psa_score_bands_finish_kernel(PsaBandsArgs P)
         if ((int)threadIdx.x < o) { redA[threadIdx.x] = max(redA[threadIdx.x], redA[threadIdx.x + o]); redB[threadIdx.x] = max(redB[threadIdx.x], redB[threadIdx.x + o]); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { A.out[pa] = max(redA[0], -100); A.out[pb] = max(redB[0], -100); }
+    const bool poisoned = P.status != nullptr && *P.status != 0u;
+    if (threadIdx.x == 0) { A.out[pa] = poisoned ? INT32_MIN : max(redA[0], -100); A.out[pb] = poisoned ? INT32_MIN : max(redB[0], -100); }
 }
 
 void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream)

@@ -28,6 +28,7 @@ struct PsaTraceArgs {
     int M, X, E, O;
     // persistent form (one launch, flag hand-off between bands): ticket word, steps completed per band, error bits
     unsigned* ticket; int* progress; unsigned* status;
+    int test_abandon;               // test hook (handoff.h): the holder of ticket test_abandon-1 never publishes; 0 = off
 };
 
 template <int R> struct TraceCfg {
@@ -56,6 +57,7 @@ struct PsaTracePackedArgs {
     unsigned* ticket; int* progress; unsigned* status;
     // ... its tiles in the order the launch pipeline runs them: "launch" d = tiles tile_first[d] .. tile_first[d+1] = bands tile_glo[d] ...
     const int* tile_first; const int* tile_glo; int n_d, n_tiles;
+    int test_abandon;               // test hook (handoff.h): the holder of ticket test_abandon-1 never publishes; 0 = off
 };
 
 // ints of per-lane state a packed band keeps between tiles: hl/fb[R], hd, hbot, ebot, cch, mxA, mxB, baseA, baseB, in_star, cch2
