@@ -9,6 +9,11 @@ of the batch, inputs already resident in HBM, followed (N>1) by the RCCL all-gat
 collective on the path.  Workload = BASELINE.json config #5 per-GPU shard (independent pairs, weak scaling):
 PAIRS_PER_GPU pairs of LEN x LEN random DNA per GPU, default scoring (M=2 X=-5 E=-2 O=-4).
 
+Every rank re-scores --verify-pairs pairs of ITS shard (drawn from a per-run seed, printed) with the reference binary and the
+mismatch count is all-reduced; the line carries per-rank ms min/max.  At N = 1 the line also carries `configs`: BASELINE
+configs #2, #3, #4 and the 64 x 50 kbp traceback batch, each with kernel ms (HIP events), wall ms, GCUPS, its SURVEY 8(d)
+roofline, a `verified` flag (reference data) and the reference's CPU path beside it (bench_configs.py).
+
 Rank 0 prints ONE JSON line with `roofline` (HBM, algorithmic bytes; plus the VALU roofline that
 actually bounds this integer recurrence) and `cpu_baseline` (the reference's own AVX512+pthreadpool binary from
 oracle/_ref timed on this host's cores on a bounded sample; falls back to the scalar oracle port).
@@ -55,6 +60,9 @@ def parse():
     ap.add_argument("--no-related", action="store_true", help="skip the extra pass over related (5 %% divergent) pairs")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of sampled scores against the reference / oracle")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--verify-pairs", type=int, default=32, help="pairs of EVERY rank's shard re-scored by the reference (drawn from a per-run seed)")
+    ap.add_argument("--verify-seed", type=int, default=0, help="0 = from the clock (printed in the JSON line)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs #2 / #3 / #4 / 5t (N = 1 only; bench_configs.py)")
     return ap.parse_args()
 
 
@@ -135,18 +143,25 @@ def reference_binary():
 
 def reference_scores(pairs, cores):
     """maxsorce (psa.c:666) of every (a, b) pair of uint8 arrays as the REFERENCE computes it: its own binary, one process
-    per pair; where that binary cannot run, the scalar oracle port.  -> (scores, "reference" | "port")"""
+    per pair (several at a time: one pair's block anti-diagonals cannot feed more than ~32 threads); where that binary
+    cannot run, the scalar oracle port.  -> (scores, "reference" | "port")"""
+    from concurrent.futures import ThreadPoolExecutor
     from tests import util
     binary = reference_binary()
     if binary:
         try:
-            got = []
+            longest = max([max(len(a), len(b)) for a, b in pairs] + [1])
+            t_each = max(1, min(cores, 32 if longest >= 20000 else 4))
+            workers = max(1, cores // t_each)
             with tempfile.TemporaryDirectory() as td:
-                for i, (a, b) in enumerate(pairs):
+                def one(i):
+                    a, b = pairs[i]
                     fa, fb = os.path.join(td, "a%d.fa" % i), os.path.join(td, "b%d.fa" % i)
                     util.write_fasta(fa, "a", a); util.write_fasta(fb, "b", b)
-                    so = run_reference(binary, min(cores, 64), fa, fb)
-                    got.append(int(so.decode().split("maxsorce=")[1].split()[0]))
+                    so = run_reference(binary, t_each, fa, fb, limit=120.0)
+                    return int(so.decode().split("maxsorce=")[1].split()[0])
+                with ThreadPoolExecutor(max_workers=workers) as ex:
+                    got = list(ex.map(one, range(len(pairs))))
             return got, "reference"
         except Exception as ex:
             sys.stderr.write("reference_scores: reference binary failed (%r); using the oracle port\n" % (ex,))
@@ -338,10 +353,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    my_kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+    rank_ms = [[dt / max(1, args.steps) * 1e3, my_kern_ms]]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor(rank_ms[0], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        allt = torch.empty(2 * world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allt, t)
+        rank_ms = allt.cpu().view(world, 2).tolist()
+        dt = max(r[0] for r in rank_ms) * 1e-3 * max(1, args.steps)          # MAX over ranks
     # which devices took part: all-gather of the 16-byte device UUIDs (a rehearsal on one GPU shows ONE distinct UUID)
     uuid = tsta_amd.device_uuid(local_rank)
     uuids = [uuid]
@@ -378,12 +397,36 @@ def main():
     except AttributeError:
         cores = os.cpu_count() or 1
 
-    # the scores of the shard that was just timed, tied to the reference (psa.c:666): a few of its pairs go back to the host
-    # and through oracle/_ref/TSTA_psa_notrace (the scalar oracle port where that binary cannot run)
+    # the scores of the shard that was just timed, tied to the reference (psa.c:666): EVERY rank sends --verify-pairs pairs of
+    # ITS shard — drawn from a per-run seed that goes into the JSON line — back to the host and through
+    # oracle/_ref/TSTA_psa_notrace (the scalar oracle port where that binary cannot run), the host cores split across the
+    # ranks; the mismatch counts are all-reduced and rank 0 requires the sum to be 0: an N-rank run proves N shards.
     verified = None
-    if rank == 0 and not args.no_verify:
-        picks = sorted({0, 1, P // 2, P - 1} & set(range(P)))
-        verified = verify_against_reference(seqs, off1.cpu().numpy(), len1.cpu().numpy(), off2.cpu().numpy(), len2.cpu().numpy(), sc, picks, cores)
+    vseed = args.verify_seed or (int(time.time()) & 0x7fffffff)
+    if world > 1:
+        vs = torch.tensor([vseed], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.broadcast(vs, src=0)
+        vseed = int(vs.item())
+    if not args.no_verify:
+        picks = sorted(int(x) for x in np.random.default_rng([vseed, rank]).choice(P, min(P, max(1, args.verify_pairs)), replace=False))
+        my_cores = max(1, cores // world)
+        bad, info = 0, None
+        try:
+            info = verify_against_reference(seqs, off1.cpu().numpy(), len1.cpu().numpy(), off2.cpu().numpy(), len2.cpu().numpy(), sc, picks, my_cores)
+        except AssertionError as ex:
+            bad = 1
+            log("rank %d: VERIFICATION FAILED: %s" % (rank, ex))
+        checked = len(picks)
+        if world > 1:
+            t = torch.tensor([bad, checked], dtype=torch.int64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            bad, checked = int(t[0].item()), int(t[1].item())
+        assert bad == 0, "%d rank(s) computed scores that differ from the reference" % bad
+        verified = {"verified_pairs": checked, "verified_ranks": world, "verify_seed": vseed,
+                    "verified_by": info["verified_by"] if info else None, "pairs": info["pairs"] if info else None,
+                    "scores": info["scores"] if info else None,
+                    "verify_note": "every rank re-scored %d pairs of its own shard (numpy default_rng([verify_seed, rank]).choice) with the "
+                                   "reference binary on %d of the host's %d cores; mismatching ranks all-reduced: 0" % (len(picks), my_cores, cores)}
 
     # a shard of RELATED pairs (second sequence = first with 5 % substitutions): real workloads are not iid DNA; the
     # running-max elision then applies to every band except those the high-scoring diagonal crosses
@@ -409,7 +452,8 @@ def main():
         if not args.no_verify:
             rsc = rscores.cpu().numpy()
             related.update(verify_against_reference(rseqs, roff1.cpu().numpy(), rlen1.cpu().numpy(), roff2.cpu().numpy(),
-                                                    rlen2.cpu().numpy(), rsc, sorted({0, P - 1}), cores))
+                                                    rlen2.cpu().numpy(), rsc,
+                                                    sorted(int(x) for x in np.random.default_rng([vseed, 99]).choice(P, min(P, 8), replace=False)), cores))
         del rseqs
 
     if rank == 0:
@@ -469,6 +513,9 @@ def main():
                                  "band, ~1 % of HBM bandwidth"},
             "valu_roofline": valu,
         }
+        out["rank_ms_per_step"] = {"min": min(r[0] for r in rank_ms), "max": max(r[0] for r in rank_ms),
+                                   "kernel_min": min(r[1] for r in rank_ms), "kernel_max": max(r[1] for r in rank_ms),
+                                   "per_rank": [round(r[0], 3) for r in rank_ms]}
         out["ranks_seen"] = len(set(uuids))
         out["device_uuids"] = uuids
         out["build_info"] = tsta_amd.build_info()
@@ -480,6 +527,16 @@ def main():
             out["generic_path"] = {"value": float(P) * L * L / (generic_ms * 1e-3) / 1e9, "unit": "GCUPS", "ms": generic_ms,
                                    "ops_per_cell": VALU_OPS_PER_CELL_GENERIC,
                                    "note": "same shard, psa_elide=0 psa_perm=0: no data-dependent shortcut; identical scores"}
+        if world == 1 and not args.no_configs:
+            # BASELINE configs #2 / #3 / #4 and the traceback batch, each with its SURVEY 8(d) roofline, verified against the
+            # reference's data and with the reference's CPU path beside it (bench_configs.py); the device is theirs now
+            try:
+                del seqs
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            from bench_configs import measure_configs
+            out["configs"] = measure_configs(eng, cores=cores, verify=not args.no_verify, cpu=not args.no_cpu_baseline, log=log)
         if not args.no_cpu_baseline and world == 1:
             n_s = args.cpu_sample_pairs or min(256, max(4, int(round(16 * (50_000.0 / L) ** 2))))
             log("cpu_baseline")

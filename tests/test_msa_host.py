@@ -70,13 +70,33 @@ def test_msa_usage_matches_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("idx", [i for i, g in enumerate(GOLDEN) if g["kind"] == "example" or i % 4 == 0])
+@pytest.mark.parametrize("idx", range(len(GOLDEN)))
 def test_msa_cli_on_gpu(tmp_path, idx):
     c = GOLDEN[idx]
     sc = c["scoring"]
     out = str(tmp_path / "out.txt")
     r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O",
                         str(sc["O"]), "-T", "4", "-i", input_path(c, tmp_path), "-o", out], capture_output=True, timeout=600)
+    check(c, r, out)
+
+
+# ---- long families (tests/golden/msa_long_golden.json, made by make_msa_long_golden.py from the compiled reference): the
+# lengths the reference's README recommends the tool for (README.md:42-43).  3 x 30 kbp: K4d with 235 chunks, the linked walker
+from tests.golden.make_msa_long_golden import long_case_seqs  # noqa: E402
+
+with open(os.path.join(util.GOLDEN_DIR, "msa_long_golden.json")) as _f:
+    LONG_GOLDEN = json.load(_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(LONG_GOLDEN)))
+def test_long_msa_cli_on_gpu(tmp_path, idx):
+    c = LONG_GOLDEN[idx]
+    sc = c["scoring"]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, long_case_seqs(c))
+    r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O",
+                        str(sc["O"]), "-T", "4", "-i", fa, "-o", out], capture_output=True, timeout=600)
     check(c, r, out)
 
 
