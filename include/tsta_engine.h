@@ -80,8 +80,12 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *   "poa_cols"         0 auto | 2 / 4      columns per lane of the POA fill kernel
  *   "align_ws_gb"      0 auto (default: tsta_psa_align_batch works in groups of <= 16 GB of trace on an engine's first call,
  *                      64 GB on the second, everything after that: device memory costs ~35 ms per GB to allocate) | cap in GB
- *   "trace_lds"        1 (default): single-pair trace fill hands the bottom row of three of every four bands to the next band
+ *   "trace_lds"        1 (default; 2: also with more workgroups than compute units): single-pair trace fill hands the bottom row of three of every four bands to the next band
  *                      through LDS rings inside a workgroup (psa_trace_quad_kernel) | 0: every hand-off through memory
+ *   "trace_split"      1 (default): single-pair trace fill with >= 16 bands runs the bands as SOLVERS (the sweep without the trace
+ *                      bytes: only what the next step needs is on the chain of dependent steps) and computes the trace bytes in
+ *                      independent EMITTER tiles that restart from checkpoints the solvers leave (psa_trace_split_kernel) | 0: never |
+ *                      2: at any size (tests)
  *   "poa_dataflow"     1 (default): POA fill as one launch, one workgroup per 128-column chunk with a solver wave, four emitter
  *                      waves and a fetcher wave (poa_dataflow.hip; sequences without 'N').  Roles are tickets drawn in start
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)

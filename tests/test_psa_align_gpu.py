@@ -92,14 +92,14 @@ def test_full_size_100k_md5_matches_reference(eng):
     x = util.random_dna(g["seed_x"], g["len_x"]); y = util.mutate(x, g["seed_y"], g["rate"])
     assert len(y) == g["len_y"]
     try:
-        for persistent, lds in ((1, 1), (1, 0), (0, 1)):
-            eng.set_option("trace_persistent", persistent); eng.set_option("trace_lds", lds)
+        for persistent, lds, split in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)):   # split (default) / quad / memory-linked / launches
+            eng.set_option("trace_persistent", persistent); eng.set_option("trace_lds", lds); eng.set_option("trace_split", split)
             ms, ra, rb = eng.psa_align(x, y)
             data = b">1\n" + ra + b"\n>2\n" + rb                      # what TSTA_psa writes (psa.c:512-516)
             assert ms == g["maxsorce"] and len(data) == g["size"]
             assert hashlib.md5(data).hexdigest() == g["md5"] and hashlib.sha256(data).hexdigest() == g["sha256"], persistent
     finally:
-        eng.set_option("trace_persistent", 1); eng.set_option("trace_lds", 1)
+        eng.set_option("trace_persistent", 1); eng.set_option("trace_lds", 1); eng.set_option("trace_split", 1)
 
 
 def test_single_launch_fill_vs_tile_pipeline(eng):
@@ -112,11 +112,14 @@ def test_single_launch_fill_vs_tile_pipeline(eng):
             for (l1, l2) in [(70, 64), (129, 128), (1000, 257), (3001, 2999), (9000, 8200)]:
                 a = util.random_dna(l1 * 3 + l2 + R, l1); b = util.mutate(a, l1 + R, 0.08)[:l2]
                 eng.set_option("trace_persistent", 1); got1 = eng.psa_align(a, b)      # R=2: four bands per workgroup linked through LDS
+                eng.set_option("trace_split", 2); got3 = eng.psa_align(a, b)           # R=2: ... as solvers, the trace from emitter tiles (forced at any size)
+                eng.set_option("trace_split", 0); got4 = eng.psa_align(a, b)
+                eng.set_option("trace_split", 1)
                 eng.set_option("trace_lds", 0); got2 = eng.psa_align(a, b)             # every hand-off through memory
                 eng.set_option("trace_lds", 1)
                 eng.set_option("trace_persistent", 0); got0 = eng.psa_align(a, b)
                 o = util.oracle_align(a, b)
-                assert got1 == got2 == got0 == (o[0], o[2], o[3]), (R, l1, l2)
+                assert got1 == got2 == got3 == got4 == got0 == (o[0], o[2], o[3]), (R, l1, l2)
         eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 0)
         pairs = []
         for i in range(48):
@@ -130,6 +133,7 @@ def test_single_launch_fill_vs_tile_pipeline(eng):
             assert (ms, ra, rb) == (o[0], o[2], o[3])
     finally:
         eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 1); eng.set_option("trace_lds", 1)
+        eng.set_option("trace_split", 1)
 
 
 def test_rows_per_lane_4_variant(eng):

@@ -106,11 +106,14 @@ def test_band_pipeline_device_form_poisons(eng):
         hip.free()
 
 
-@pytest.mark.parametrize("variant", ["quad", "memory", "rows4"])
+@pytest.mark.parametrize("variant", ["split", "quad", "memory", "rows4"])
 def test_single_pair_trace_fill_runs_again(eng, variant):
-    # tsta_psa_align: psa_trace_quad_kernel (four bands per workgroup, LDS-linked) / psa_trace_tile_kernel<.., PERSIST>
+    # tsta_psa_align: psa_trace_split_kernel (solver bands + emitter tiles) / psa_trace_quad_kernel (four bands per
+    # workgroup, LDS-linked) / psa_trace_tile_kernel<.., PERSIST>
     a = util.random_dna(31, 9000); b = util.mutate(a, 32, 0.08)[:8200]
     o = util.oracle_align(a, b)
+    if variant == "quad":
+        eng.set_option("trace_split", 0)
     if variant == "memory":
         eng.set_option("trace_lds", 0)
     if variant == "rows4":

@@ -1,0 +1,12 @@
+import sys, time, json, hashlib, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tsta_amd
+from tests import util
+g = json.load(open(os.path.join(util.GOLDEN_DIR, 'psa_big_golden.json')))
+x = util.random_dna(g["seed_x"], g["len_x"]); y = util.mutate(x, g["seed_y"], g["rate"])
+eng = tsta_amd.Engine(0)
+ks = []
+for i in range(6):
+    ms, ra, rb = eng.psa_align(x, y)
+    ks.append(round(eng.last_kernel_ms()[0], 3))
+print(os.environ.get("TSTA_SPLIT_EMIT_WG"), os.environ.get("TSTA_SPLIT_NOEMIT"), "kernel_ms", ks, flush=True)

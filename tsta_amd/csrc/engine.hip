@@ -179,7 +179,7 @@ void tsta_engine_destroy(tsta_engine* eng)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
-                            &e->scratch2, &e->pair_flags, &e->unpacked, &e->unpacked2}) {
+                            &e->scratch2, &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
         if (b->p) (void)hipFree(b->p);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -202,7 +202,7 @@ int tsta_engine_release_workspaces(tsta_engine* eng)
     if ((rc = e->check(hipStreamSynchronize(e->stream), "hipStreamSynchronize")) != TSTA_OK) return rc;
     // everything but the small counter block (ticket words, self-test / result scalars)
     for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
-                            &e->pair_flags, &e->unpacked, &e->unpacked2}) {
+                            &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr; b->bytes = 0;
     }
@@ -226,8 +226,9 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
-    if (!strcmp(key, "trace_lds") && (v == 0 || v == 1)) { e->opt_trace_lds = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_lds") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_lds = v; return TSTA_OK; }
     if (!strcmp(key, "poa_dataflow") && (v == 0 || v == 1 || v == 2)) { e->opt_poa_dataflow = v; return TSTA_OK; }
+    if (!strcmp(key, "trace_split") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_split = v; return TSTA_OK; }
     if (!strcmp(key, "test_abandon") && v >= 0) { e->opt_test_abandon = v; return TSTA_OK; }
     if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }

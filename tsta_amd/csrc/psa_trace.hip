@@ -26,6 +26,7 @@
 // emitted; cells outside the window (band crossings) are read straight from HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -145,7 +146,9 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
 // a step.  Flow control at the same moments: the reader waits until the writer's `done` word covers its G columns (writer
 // 64+G steps ahead), the writer until the reader is less than a ring behind.  The distance between two such bands is
 // 80-95 steps instead of the 128 + ~25 (latency) of the hand-off through memory (measured on 100 kbp: G = 8: 28.4 ms, 16: 27.6, 32: 27.8).
-constexpr int kRing = 1024;                               // entries per ring (power of two); + 64 dummy entries for the lanes that store nothing
+constexpr int kRing = 4096;                               // entries per ring (power of two); + 64 dummy entries for the lanes that store nothing
+                                                          // (3 rings = 98 KB of LDS: at most ONE such workgroup per compute unit, on purpose — two
+                                                          // workgroups of bands on one CU would put two chain waves on every SIMD)
 struct LdsLink {
     int2* ring_top;  int* done_up;                        // ring the band reads its top row from / steps the band above has finished (null: memory)
     int2* ring_bot;  int* done_down;                      // ring its bottom row goes to / steps the band below has finished (null: memory)
@@ -166,7 +169,7 @@ __device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* statu
 
 constexpr int kLinkG = 16;                                // columns per LDS hand-off (16 / R steps make one trace group: G is a multiple of it)
 
-template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT>
+template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true>
 __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                                    const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
                                                    const LdsLink& L, const int S_total, unsigned* status)
@@ -193,13 +196,15 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
             int tb[(R + 3) / 4];
 #pragma unroll
             for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
-            trace_step<R, PRED, true, FULL>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
-            if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
+            trace_step<R, PRED, TRACE, FULL>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
+            if constexpr (!TRACE) { (void)acc; }
+            else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
             else { acc[(q * R) / 4] = (tb[0] << (8 * ((q * R) % 4))) + acc[(q * R) / 4]; }
         }
-        tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
-                                        (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
+        if constexpr (TRACE)
+            tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
+                                            (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
         if (((ts + SPB) & (G - 1)) == 0) {
             const int te = ts + SPB;                         // steps finished; lanes 64-G..63 of (sh, se) hold columns te-64-G .. te-65
             if (LBOT) {
@@ -220,22 +225,24 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
 // A workgroup's four bands are a ticket drawn when it starts (HIP promises no dispatch order): the band a workgroup's first wave
 // waits for belongs to a workgroup that started earlier, so the waits end whatever the residency.  (The host still launches this
 // form only when there are no more workgroups than compute units: queued workgroups would only lengthen the chain.)
-template <int R>
-__global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
+//
+// SPLIT (psa_trace_split_kernel below): the bands are SOLVERS — the same sweep without the trace bytes, i.e. only what the
+// next step and the next band need (~31 instead of ~56 VALU instructions per R = 2 step on the chain of dependent steps).
+// Every band additionally leaves in memory what an EMITTER wave needs to compute the trace bytes of a C-step tile of the band
+// on its own, off the chain: its bottom row (every band, not only a workgroup's last) and its lane state at every multiple of
+// C steps (`ckpt`); `eprog[band]` says how far both have been published.  That publication is deferred by one 64-step block:
+// the wave drains its stores (s_waitcnt vmcnt(0)) before the stores of the current block are issued, when those of the
+// previous block have long landed, so the drain costs nothing on the chain.
+template <int R, bool SPLIT>
+__device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, const int wave, const int lane, int2 (*ring)[kRing + 64], int* done)
 {
     constexpr int NS = TraceCfg<R>::NS;
     constexpr int SPB = TraceCfg<R>::SPB;
-    __shared__ int2 ring[3][kRing + 64];
-    __shared__ int done[4];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    __shared__ int wg_s;
-    if (threadIdx.x < 4) done[threadIdx.x] = 0;
-    if (threadIdx.x == 0) wg_s = (int)atomicAdd(A.ticket, 1u);
-    __syncthreads();
+    constexpr bool TRACE = !SPLIT;
     const TraceJob& J = A.jobs[0];
-    const int w = __builtin_amdgcn_readfirstlane(wg_s) * 4 + wave, g = J.band0 + w;
+    const int w = wg * 4 + wave, g = J.band0 + w;
     if (w >= J.W) return;
-    const bool mute = A.test_abandon != 0 && __builtin_amdgcn_readfirstlane(wg_s) == A.test_abandon - 1;   // test hook: never publishes
+    const bool mute = A.test_abandon != 0 && wg == A.test_abandon - 1;   // test hook: never publishes
     const int n = J.n, m = J.m, M = A.M, X = A.X, E = A.E, O = A.O, S_total = J.S_total;
     const uint8_t* __restrict__ seq_a = J.a;
     const uint8_t* __restrict__ seq_b = J.b;
@@ -263,6 +270,9 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
     const int2* __restrict__ top = J.rows + (size_t)w * J.row_stride;
     int2* __restrict__ bot = J.rows + (size_t)(w + 1) * J.row_stride;
     uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
+    int pending = 0;                                          // SPLIT: steps whose stores have been issued but not yet published
+    unsigned long long clk0 = 0;
+    if (SPLIT && A.dbg) clk0 = __builtin_amdgcn_s_memrealtime();
 
     for (int t0 = 0; t0 < S_total; t0 += 64) {
         const int c = t0 + lane;
@@ -280,25 +290,146 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
         const bool full = (w + 1) * 64 * R <= m;
 #define TSTA_LINKED(PRED_, FULL_)                                                                                                        \
         do {                                                                                                                             \
-            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
-            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else                     trace_block_linked<R, PRED_, FULL_, false, false>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status); \
+            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
+            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status); \
         } while (0)
         if (steady && full) TSTA_LINKED(false, true);
         else if (steady)    TSTA_LINKED(false, false);
         else                TSTA_LINKED(true, false);
 #undef TSTA_LINKED
-        if (!bot_lds) {
-            const int cs = t0 - 64 + lane;
+        if (SPLIT && A.dbg && t0 == 0) clk0 = __builtin_amdgcn_s_memrealtime();
+        const int cs = t0 - 64 + lane;
+        if (SPLIT) {
+            // what the previous block left in memory has had this block's time to land: publish it to the emitters
+            if (pending > 0 && !mute) publish_progress(&A.eprog[g], pending, lane);
+            if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
+            const int te = t0 + 64;
+            if (te % A.C == 0 && te < S_total) {                // lane state at step te: where an emitter tile of this band starts
+                int* ck = A.ckpt + ((size_t)g * A.NC + te / A.C) * NS * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < R; ++k) { store_sc1_int(&ck[(2 * k) * 64], s.hl[k]); store_sc1_int(&ck[(2 * k + 1) * 64], s.fb[k]); }
+                store_sc1_int(&ck[(2 * R) * 64], s.hd); store_sc1_int(&ck[(2 * R + 1) * 64], s.hbot); store_sc1_int(&ck[(2 * R + 2) * 64], s.ebot);
+                store_sc1_int(&ck[(2 * R + 3) * 64], s.cch);
+            }
+            pending = te;
+            if (!bot_lds && !mute) publish_progress(&A.progress[g], te, lane);      // the next workgroup's first band waits for this one
+        } else if (!bot_lds) {
             if (cs >= 0 && cs < n) store_sc1_int2(&bot[cs], s.sh, s.se);
             if (!mute) publish_progress(&A.progress[g], t0 + 64, lane);
         }
     }
+    if (SPLIT && !mute) publish_progress(&A.eprog[g], S_total, lane);
+    if (SPLIT && A.dbg && lane == 0) { A.dbg[2 * g] = clk0; A.dbg[2 * g + 1] = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = s.hl[k]; st[(2 * k + 1) * 64] = s.fb[k]; }
     st[(2 * R) * 64] = s.hd; st[(2 * R + 1) * 64] = s.hbot; st[(2 * R + 2) * 64] = s.ebot;
     st[(2 * R + 3) * 64] = s.cch; st[(2 * R + 4) * 64] = s.mx;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
+{
+    __shared__ int2 ring[3][kRing + 64];
+    __shared__ int done[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ int wg_s;
+    if (threadIdx.x < 4) done[threadIdx.x] = 0;
+    if (threadIdx.x == 0) wg_s = (int)atomicAdd(A.ticket, 1u);
+    __syncthreads();
+    quad_band<R, false>(A, __builtin_amdgcn_readfirstlane(wg_s), wave, lane, ring, done);
+}
+
+// ---- split form: solvers on the chain, emitters beside it ----------------------------------------------------------------
+// The chain of dependent steps of ONE pair is what its fill costs (n + bands x ~100 steps, one wave per band, a lone wave
+// issuing one VALU instruction every ~5.2 cycles): the fewer instructions a step has, the shorter the fill.  Of the ~56
+// instructions of an R = 2 step only ~31 feed the next step or the next band; the rest build and pack the trace byte.  Here
+// the workgroups that start first (tickets below n_solver_wg) are the solvers of quad_band<R, true>; every other wave of the
+// launch is an EMITTER: it draws a tile (band w, steps [cC, (c+1)C)) — tiles are numbered along the diagonals u = w + cK, the
+// order in which the solvers make them available — waits until the band's checkpoint at step cC and the upper band's bottom
+// row up to (c+1)C + 64 have been published (eprog), restores the lane state, and runs the same steps again WITH the trace
+// bytes (the unchanged trace_block of the launch pipeline), storing nothing but the trace.  Emitter tiles are independent of
+// each other: they fill the SIMDs the ramp of the bands leaves idle, the compute units the solvers do not occupy and the
+// issue slots a lone solver wave cannot use (solvers run at the highest wave priority, emitters at the lowest).  Total work
+// grows (every cell is computed twice), the chain shrinks; the trace bytes are the same bytes.
+// Workgroups of EIGHT waves, one per compute unit (the rings' LDS sees to that): waves 0-3 of a solver workgroup are its four
+// bands, one per SIMD; waves 4-7 — and all eight waves of the workgroups beyond the solvers — are emitters.
+constexpr int kSplitThreads = 512;
+template <int R>
+__global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTraceArgs A)
+{
+    constexpr int NS = TraceCfg<R>::NS;
+    constexpr int SPB = TraceCfg<R>::SPB;
+    __shared__ int2 ring[3][kRing + 64];
+    __shared__ int done[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ int wg_s;
+    if (threadIdx.x < 4) done[threadIdx.x] = 0;
+    if (threadIdx.x == 0) wg_s = (int)atomicAdd(A.ticket, 1u);
+    __syncthreads();
+    const int wg = __builtin_amdgcn_readfirstlane(wg_s);
+    if (wg < A.n_solver_wg && wave < 4) {
+        __builtin_amdgcn_s_setprio(3);
+        quad_band<R, true>(A, wg, wave, lane, ring, done);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const TraceJob& J = A.jobs[0];
+    const int n = J.n, M = A.M, X = A.X, E = A.E, O = A.O, S_total = J.S_total;
+    const uint8_t* __restrict__ seq_a = J.a;
+    const uint8_t* __restrict__ seq_b = J.b;
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(A.tile_ticket, 1u);
+        const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
+        if (t >= A.n_tiles) return;
+        int lo = 0, hi = A.n_diag - 1;          // diagonal u = last one whose first tile is <= t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.diag_first[mid] <= t) lo = mid; else hi = mid - 1; }
+        const int u = lo;
+        const int c_lo = max(0, (u - (J.W - 1) + A.K - 1) / A.K);
+        const int c = c_lo + (t - A.diag_first[u]);
+        const int w = u - c * A.K, g = J.band0 + w;
+        const int s0 = c * A.C, s1 = min(S_total, s0 + A.C);
+        if (s0 > 0) wait_progress(&A.eprog[g], s0, A.status, lane);                            // the band's checkpoint at s0
+        if (w > 0)  wait_progress(&A.eprog[g - 1], min(s1 + 64, S_total), A.status, lane);     // the upper band's bottom row, 64 steps further
+        const int i0 = w * 64 * R + lane * R;
+        TLane<R> s;
+#pragma unroll
+        for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < J.m) ? (int)seq_b[i0 + k] : 0x100;
+        if (s0 == 0) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int hk = hcol0t(i0 + 1 + k, E, O);
+                s.hl[k] = hk;
+                s.fb[k] = hk + O;
+            }
+            s.hd = hcol0t(i0, E, O);
+            s.hbot = 0; s.ebot = 0; s.cch = 0;
+        } else {
+            const int* ck = A.ckpt + ((size_t)g * A.NC + c) * NS * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { s.hl[k] = load_sc1_int(&ck[(2 * k) * 64]); s.fb[k] = load_sc1_int(&ck[(2 * k + 1) * 64]); }
+            s.hd = load_sc1_int(&ck[(2 * R) * 64]); s.hbot = load_sc1_int(&ck[(2 * R + 1) * 64]); s.ebot = load_sc1_int(&ck[(2 * R + 2) * 64]);
+            s.cch = load_sc1_int(&ck[(2 * R + 3) * 64]);
+        }
+        s.mx = kNegInfT; s.sh = 0; s.se = 0;
+        const int2* __restrict__ top = J.rows + (size_t)w * J.row_stride;
+        uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
+        for (int t0 = s0; t0 < s1; t0 += 64) {
+            const int cc = t0 + lane;
+            int2 nt = make_int2(0, 0); int na = 0;
+            if (cc < n) {
+                nt = (w > 0) ? load_sc1_int2(&top[cc]) : top[cc];
+                na = seq_a[cc];
+            }
+            s.th = nt.x; s.te = nt.y; s.ach = na;
+            uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
+            // (FULL: the running maximum is the solvers' business — nothing here reads s.mx)
+            if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, true, false, true>(s, t0, lane, n, R, M, X, E, O, tq);
+            else                         trace_block<R, true, true, false, true>(s, t0, lane, n, R, M, X, E, O, tq);
+        }
+    }
 }
 
 // PERSIST = false: one tile of the launch-per-diagonal pipeline (see file header).
@@ -705,13 +836,20 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     }
     if (single_bands > 0x7fffffff || couple_bands > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
     const size_t jobs_b = ((size_t)(n_jobs + n_singles) * sizeof(TraceJob) + 255) / 256 * 256;
+    // split form (one pair: solvers + emitters, psa_trace_split_kernel): emitter tiles of kSplitC steps, numbered along u = w + c*K
+    constexpr int kSplitC = 1024, kSplitK = 8;
+    size_t split_tab_ints = 0;
+    if (TRACE && n_jobs == 1) {
+        const JobGeom<R> g0(jobs[0].n, jobs[0].m, true);
+        split_tab_ints = (size_t)g0.W + (size_t)(g0.S_total / kSplitC + 2) * kSplitK + 8;
+    }
     const size_t couples_b = ((size_t)n_couples * sizeof(TraceCouple) + 255) / 256 * 256;
     int rc;
     if ((rc = e->reserve(e->in_seqs, seq_b, "hipMalloc(seqs)")) ||
         (rc = e->reserve(e->rows, rows_b, "hipMalloc(rows)")) ||
         (rc = e->reserve(e->scratch, state_b + 256, "hipMalloc(state)")) ||
         (rc = e->reserve(e->in_meta, jobs_b + couples_b + ((size_t)n_jobs * 8 * sizeof(int) + 255) / 256 * 256 +
-                                         ((size_t)single_bands + (size_t)couple_bands + 2 * (size_t)d_bound + 256) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
+                                         (3 * (size_t)single_bands + (size_t)couple_bands + 2 * (size_t)d_bound + split_tab_ints + 256) * sizeof(int) + 256, "hipMalloc(jobs)")) ||
         (TRACE && (rc = e->reserve(e->trace, trace_b, "hipMalloc(trace)"))) ||
         (TRACE && (rc = e->reserve(e->scratch2, ops_b, "hipMalloc(ops)"))))
         return rc;
@@ -773,8 +911,9 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     A.jobs = d_singles; A.n_jobs = n_singles; A.T = T; A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.ticket = reinterpret_cast<unsigned*>(d_sync); A.status = reinterpret_cast<unsigned*>(d_sync + 1); A.progress = d_sync + 64;
     A.test_abandon = e->opt_test_abandon;
+    A.dbg = nullptr; A.eprog = nullptr; A.ckpt = nullptr; A.C = 0; A.NC = 0; A.K = 1; A.n_solver_wg = 0; A.tile_ticket = nullptr; A.diag_first = nullptr; A.n_diag = 0; A.n_tiles = 0;
     if ((persistent || persistent_couples) &&
-        (rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int), s), "hipMemsetAsync(sync)")))
+        (rc = e->check(hipMemsetAsync(d_sync, 0, (2 * (size_t)single_bands + (size_t)couple_bands + 128) * sizeof(int), s), "hipMemsetAsync(sync)")))
         return rc;
     PsaTracePackedArgs B;
     B.jobs = d_jobs; B.couples = d_couples; B.n_couples = n_couples; B.T = T; B.M = p->M; B.X = p->X; B.E = p->E; B.O = p->O;
@@ -844,11 +983,53 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if (e->side[0] && e->ev_join[0] && e->ev_fork &&
             hipEventRecord(e->ev_fork, s) == hipSuccess && hipStreamWaitEvent(e->side[0], e->ev_fork, 0) == hipSuccess) { ss = e->side[0]; single_on_side = true; }
     }
-    if (persistent && !persistent_couples && TRACE && R == 2 && e->opt_trace_lds != 0 && (single_bands + 3) / 4 <= e->n_cu) {
-        // one pair, few enough bands that every workgroup of four is resident: bands linked through LDS inside a workgroup
-        A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
-        hipLaunchKernelGGL((psa_trace_quad_kernel<2>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
-        ++launches;
+    bool quad = false;
+    std::vector<int> diag_tab;
+    if constexpr (TRACE && R <= 2) {
+        quad = persistent && !persistent_couples && e->opt_trace_lds != 0 && ((single_bands + 3) / 4 <= e->n_cu || e->opt_trace_lds == 2);
+        // split form: worth it once the pair has enough bands for the chain to matter (and only while every solver workgroup
+        // gets a compute unit of its own)
+        static const TraceJob none = {};
+        const TraceJob& J0 = quad ? singles[0] : none;
+        const int NC = (J0.S_total + kSplitC - 1) / kSplitC;
+        bool split = false;
+        if constexpr (R == 2) split = quad && e->opt_trace_split != 0 && (single_bands + 3) / 4 <= e->n_cu && (J0.W >= 16 || e->opt_trace_split == 2);
+        const size_t ckpt_bytes = ((size_t)J0.W * NC * TraceCfg<R>::NS * 64 * sizeof(int) + 255) / 256 * 256;
+        static const bool want_clock = getenv("TSTA_SPLIT_CLOCK") != nullptr;              // diagnostics
+        if (split && e->reserve(e->ckpt, ckpt_bytes + (want_clock ? (size_t)J0.W * 16 : 0) + 256, "hipMalloc(checkpoints)") == TSTA_OK) {
+            if (want_clock) A.dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->ckpt.p) + ckpt_bytes);
+            const int n_diag = (J0.W - 1) + (NC - 1) * kSplitK + 1;
+            diag_tab.assign((size_t)n_diag + 1, 0);
+            int64_t total = 0;
+            for (int u = 0; u < n_diag; ++u) {
+                const int c_lo = std::max(0, (u - (J0.W - 1) + kSplitK - 1) / kSplitK), c_hi = std::min(NC - 1, u / kSplitK);
+                diag_tab[(size_t)u] = (int)total;
+                total += std::max(0, c_hi - c_lo + 1);
+            }
+            diag_tab[(size_t)n_diag] = (int)total;
+            if (total != (int64_t)J0.W * NC || diag_tab.size() > split_tab_ints) return TSTA_ERR_INTERNAL;
+            int* d_eprog = d_sync + 64 + single_bands + couple_bands;                       // cleared by the memset above
+            int* d_diag = d_sync + 2 * single_bands + couple_bands + 128 + 2 * d_bound;     // behind the couples' tile table
+            if ((rc = e->check(hipMemcpyAsync(d_diag, diag_tab.data(), diag_tab.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D emitter tile table"))) return rc;
+            A.eprog = d_eprog; A.ckpt = reinterpret_cast<int*>(e->ckpt.p); A.C = kSplitC; A.NC = NC; A.K = kSplitK;
+            A.n_solver_wg = (int)((single_bands + 3) / 4);
+            A.tile_ticket = reinterpret_cast<unsigned*>(d_sync + 3); A.diag_first = d_diag; A.n_diag = n_diag; A.n_tiles = (int)total;
+            A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
+            // emitters: every compute unit ends up with two workgroups (a solver workgroup and an emitter workgroup, or two of the latter)
+            // one workgroup per compute unit (LDS): the solvers' CUs carry four emitter waves each, the others eight
+            int n_wg = std::max(e->n_cu, A.n_solver_wg);
+            if (const char* v = getenv("TSTA_SPLIT_WG")) n_wg = std::max(A.n_solver_wg, atoi(v));     // experiments
+            if (getenv("TSTA_SPLIT_NOEMIT")) A.n_tiles = 0;                                            // experiments: solvers only (no trace!)
+            if constexpr (R == 2) hipLaunchKernelGGL((psa_trace_split_kernel<2>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
+            ++launches;
+        } else if (quad) {
+            // one pair: bands linked through LDS inside a workgroup of four
+            A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
+            hipLaunchKernelGGL((psa_trace_quad_kernel<R>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
+            ++launches;
+        }
+    }
+    if (quad) {
     } else if (persistent) {                                    // the singles' whole fill in one launch (flag hand-off)
         A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
         hipLaunchKernelGGL((psa_trace_tile_kernel<R, TRACE, true>), dim3((unsigned)std::min<int64_t>((single_bands + 3) / 4, e->n_cu)), dim3(256), 0, ss, A);
@@ -872,7 +1053,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             if (total > 0x7fffffff) return TSTA_ERR_UNSUPPORTED;
         }
         tile_tab[(size_t)Dc] = (int)total;
-        int* d_tab = d_sync + single_bands + couple_bands + 128;          // behind the words the memset above clears
+        int* d_tab = d_sync + 2 * single_bands + couple_bands + 128;      // behind the words the memset above clears
         if ((rc = e->check(hipMemcpyAsync(d_tab, tile_tab.data(), tile_tab.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D tile table"))) return rc;
         B.couples = d_couples; B.n_couples = n_couples; B.d = 0; B.g_lo = 0; B.g_hi = (int)couple_bands;
         B.tile_first = d_tab; B.tile_glo = d_tab + Dc + 1; B.n_d = (int)Dc; B.n_tiles = (int)total;
@@ -914,6 +1095,18 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     if ((rc = e->check(hipMemcpyAsync(h_out.data(), d_out, h_out.size() * sizeof(int), hipMemcpyDeviceToHost, s), "D2H out")) ||
         (rc = e->check(hipStreamSynchronize(s), "psa_align sync")))
         return rc;
+    if (A.dbg) {
+        std::vector<unsigned long long> h((size_t)2 * single_bands);
+        if (e->copy_sync(h.data(), A.dbg, h.size() * 8, hipMemcpyDeviceToHost, "D2H clocks") == TSTA_OK) {
+            const double us = 0.01;                             // s_memrealtime: 100 MHz
+            fprintf(stderr, "[tsta] split solvers: band, start us, duration us, start - previous start us\n");
+            for (int64_t b = 0; b < single_bands; ++b)
+                if (b < 24 || b % 20 == 0 || b + 4 >= single_bands)
+                    fprintf(stderr, "[tsta] %5lld %10.1f %10.1f %8.2f\n", (long long)b, (double)(h[2 * b] - h[0]) * us, (double)(h[2 * b + 1] - h[2 * b]) * us,
+                            b ? (double)(h[2 * b] - h[2 * b - 2]) * us : 0.0);
+            fprintf(stderr, "[tsta] last band ends at %.1f us\n", (double)(h[2 * single_bands - 1] - h[0]) * us);
+        }
+    }
     if (persistent || persistent_couples) {
         unsigned st = 0;
         if ((rc = e->copy_sync(&st, d_sync + 1, sizeof(st), hipMemcpyDeviceToHost, "D2H status"))) return rc;

@@ -29,6 +29,13 @@ struct PsaTraceArgs {
     // persistent form (one launch, flag hand-off between bands): ticket word, steps completed per band, error bits
     unsigned* ticket; int* progress; unsigned* status;
     int test_abandon;               // test hook (handoff.h): the holder of ticket test_abandon-1 never publishes; 0 = off
+    // split form (psa_trace_split_kernel): solvers + emitters
+    int* eprog;                     // [bands]: steps up to which a band's bottom row and checkpoints are published
+    int* ckpt;                      // [bands][NC][NS][64]: lane state of a band at step c*C (c >= 1)
+    int  C, NC, K;                  // emitter tile length (steps, multiple of 64), tiles per band, tile order u = w + c*K
+    int  n_solver_wg;               // tickets below this are solver workgroups (four bands each)
+    unsigned long long* dbg;        // diagnostics (TSTA_SPLIT_CLOCK=1): [band] {s_memrealtime at the band's first step, at its last}, or null
+    unsigned* tile_ticket; const int* diag_first; int n_diag, n_tiles;   // emitter tiles: diagonal u = tickets diag_first[u] .. diag_first[u+1]
 };
 
 template <int R> struct TraceCfg {
