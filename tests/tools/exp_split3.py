@@ -1,0 +1,23 @@
+"""One-off: config #3 pair, split form with LDS-transport solvers (trace_split 1) vs lane-transport solvers (3) vs quad (0)."""
+import sys, time, json, hashlib, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tsta_amd
+from tests import util
+g = json.load(open(os.path.join(util.GOLDEN_DIR, 'psa_big_golden.json')))
+x = util.random_dna(g["seed_x"], g["len_x"]); y = util.mutate(x, g["seed_y"], g["rate"])
+eng = tsta_amd.Engine(0)
+small = [(70, 64), (129, 128), (1000, 257), (3001, 2999), (9000, 8200), (20000, 19000), (2100, 2100), (1030, 1025)]
+for mode in (2, 3):
+    eng.set_option("trace_split", mode)
+    for (l1, l2) in small:
+        a = util.random_dna(l1 * 3 + l2, l1); b = util.mutate(a, l1, 0.08)[:l2]
+        got = eng.psa_align(a, b); o = util.oracle_align(a, b)
+        print("mode", mode, l1, l2, got == (o[0], o[2], o[3]), "reruns", eng.stat("single_launch_reruns"), flush=True)
+for mode in (1, 3, 0, 1):
+    eng.set_option("trace_split", mode)
+    ks = []
+    for i in range(4):
+        ms, ra, rb = eng.psa_align(x, y)
+        ks.append(round(eng.last_kernel_ms()[0], 3))
+    data = b">1\n" + ra + b"\n>2\n" + rb
+    print("mode", mode, "kernel_ms", ks, "md5ok", hashlib.md5(data).hexdigest() == g["md5"], "reruns", eng.stat("single_launch_reruns"), flush=True)

@@ -66,7 +66,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
                                            const int M, const int X, const int E, const int O, int (&tb)[(R + 3) / 4])
 {
     unsigned hu_u, eu_u;
-    lane_exchange(reinterpret_cast<unsigned&>(s.cch), hu_u, eu_u, reinterpret_cast<unsigned&>(s.sh), reinterpret_cast<unsigned&>(s.se),
+    lane_exchange_chain(reinterpret_cast<unsigned&>(s.cch), hu_u, eu_u, reinterpret_cast<unsigned&>(s.sh), reinterpret_cast<unsigned&>(s.se),
                   reinterpret_cast<unsigned&>(s.ach), reinterpret_cast<unsigned&>(s.th), reinterpret_cast<unsigned&>(s.te),
                   (unsigned)s.hbot, (unsigned)s.ebot);
     const int hu = (int)hu_u;

@@ -57,6 +57,37 @@ __device__ __forceinline__ void lane_exchange(unsigned& cch, unsigned& hu, unsig
         : "vcc", "scc");
 }
 
+// The same hand-off for kernels whose waves run ALONE on their SIMD (the single-pair trace fills of psa_trace.hip: one wave per
+// band, the chain of dependent steps is the run time): such a wave pays ~5 cycles for every instruction it issues, scalar
+// ones included, so the block is reordered to need one VCC switch instead of two and no s_nop (10 instead of 12 issue slots).
+// Contract of the caller: sh / se are written by nothing but this block and the initialisation of a tile.
+__device__ __forceinline__ void lane_exchange_chain(unsigned& cch, unsigned& hu, unsigned& eu, unsigned& sh, unsigned& se,
+                                              unsigned& ach, unsigned& th, unsigned& te, unsigned hbot, unsigned ebot)
+{
+    // hu / eu are produced IN PLACE in the registers holding hbot / ebot (their last readers come first)
+    hu = hbot;
+    eu = ebot;
+    // Ten instructions (a lone wave pays ~5 cycles for EVERY instruction it issues, scalar ones included): the two captures
+    // first, under the lane-63 mask — they read hbot / ebot before hu / eu overwrite them in place — then everything that
+    // injects at lane 0 under ONE mask.  No s_nop: the DPP sources sh / se were last written a step ago (at a tile's first
+    // step a stale read would only shift in garbage that is shifted out again before anything is stored), cch a step ago,
+    // hbot / ebot at least four instructions before their DPP reads.
+    asm volatile(
+        "s_lshl_b64 vcc, 1, 63\n\t"
+        "v_cndmask_b32_dpp %3, %3, %1, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cndmask_b32_dpp %4, %4, %2, vcc wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_mov_b64 vcc, 1\n\t"
+        "v_cndmask_b32_dpp %0, %0, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %1, %6, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %2, %7, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(cch), "+v"(hu), "+v"(eu), "+v"(sh), "+v"(se), "+v"(ach), "+v"(th), "+v"(te)
+        :
+        : "vcc", "scc");
+}
+
 // lane_exchange for a column character that travels as TWO registers (the per-pair byte tables of the v_perm path)
 __device__ __forceinline__ void lane_exchange2(unsigned& cch, unsigned& cch2, unsigned& hu, unsigned& eu, unsigned& sh, unsigned& se,
                                                unsigned& ach, unsigned& ach2, unsigned& th, unsigned& te, unsigned hbot, unsigned ebot)
