@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include "../../include/tsta_engine.h"
+#include "cli_common.h"
 #include "fasta.h"
 
 static void print_usage(void)
@@ -36,6 +37,7 @@ static void print_usage(void)
 static int fail(tsta_engine* eng, int rc, const char* what)
 {
     fprintf(stderr, "%s: %s%s%s\n", what, tsta_strerror(rc), eng ? ": " : "", eng ? tsta_last_error(eng) : "");
+    cli_quick_exit(1);
     return 1;
 }
 
@@ -63,15 +65,16 @@ int main(int argc, char* argv[])
         print_usage();
         return 0;
     }
+    cli_engine boot;
+    cli_engine_start(&boot);                                     /* HIP start-up + engine in a helper thread while the FASTA files are read */
     fasta_file* f1 = fasta_read(input1, 1);
     fasta_file* f2 = fasta_read(input2, 1);
-    if (f1->count == 0 || f2->count == 0) { fprintf(stderr, "no FASTA record found\n"); return 1; }
+    if (f1->count == 0 || f2->count == 0) { fprintf(stderr, "no FASTA record found\n"); cli_quick_exit(1); }
     const fasta_seq* s1 = &f1->seqs[0];
     const fasta_seq* s2 = &f2->seqs[0];
 
-    const char* dev = getenv("TSTA_DEVICE");
     tsta_engine* eng = NULL;
-    int rc = tsta_engine_create(dev ? atoi(dev) : 0, &eng);
+    int rc = cli_engine_get(&boot, &eng);
     if (rc != TSTA_OK) return fail(NULL, rc, "tsta_engine_create");
     int32_t ms = 0;
 #ifdef TRACE
@@ -99,8 +102,8 @@ int main(int argc, char* argv[])
         if (rc != TSTA_OK) return fail(eng, rc, "tsta_psa_score_batch");
     }
 #endif
-    tsta_engine_destroy(eng);
-    fasta_free(f1); fasta_free(f2);
     printf("maxsorce=%d\n", ms);                                 /* psa.c:666 */
+    /* every output is written and closed: no need to walk the runtime's exit handlers (cli_common.h) */
+    cli_quick_exit(0);
     return 0;
 }

@@ -5,28 +5,33 @@
 #include <string.h>
 #include <zlib.h>
 
+/* the reference exit()s on unreadable input (seqio.c:38,47,180); here another thread may be in the middle of bringing the HIP
+ * runtime up (cli_common.h), so leave without running exit handlers */
+#include <unistd.h>
+static void fasta_die(void) { fflush(stdout); fflush(stderr); _exit(1); }
+
 static char* slurp(const char* path, size_t* out_len)
 {
     FILE* fp = fopen(path, "rb");
     if (!fp) {
         fprintf(stderr, "File %s does not exist.\n", path);
-        exit(1);
+        fasta_die();
     }
     unsigned char magic[2] = {0, 0};
     size_t got = fread(magic, 1, 2, fp);
     fclose(fp);
     size_t cap = 1 << 20, len = 0;
     char* buf = (char*)malloc(cap);
-    if (!buf) { fprintf(stderr, "out of memory\n"); exit(1); }
+    if (!buf) { fprintf(stderr, "out of memory\n"); fasta_die(); }
     /* gzread on a plain file passes the bytes through, so one code path serves both */
     gzFile gz = gzopen(path, "rb");
-    if (!gz) { fprintf(stderr, "File %s does not exist.\n", path); exit(1); }
+    if (!gz) { fprintf(stderr, "File %s does not exist.\n", path); fasta_die(); }
     (void)got; (void)magic;
     for (;;) {
         if (cap - len < (1 << 16)) {
             cap *= 2;
             buf = (char*)realloc(buf, cap);
-            if (!buf) { fprintf(stderr, "out of memory\n"); exit(1); }
+            if (!buf) { fprintf(stderr, "out of memory\n"); fasta_die(); }
         }
         int n = gzread(gz, buf + len, (unsigned)(cap - len - 1));
         if (n <= 0) break;
@@ -48,7 +53,7 @@ fasta_file* fasta_read(const char* path, size_t max_records)
     fasta_file* f = (fasta_file*)calloc(1, sizeof(fasta_file));
     if (p < len && buf[p] == '@') {
         fprintf(stderr, "Cannot read fasta record from a fastq file.\n");
-        exit(1);
+        fasta_die();
     }
     size_t cap = 0;
     while (p < len) {
