@@ -172,7 +172,8 @@ constexpr int kLinkG = 16;                                // columns per LDS han
 template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true>
 __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                                    const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
-                                                   const LdsLink& L, const int S_total, unsigned* status)
+                                                   const LdsLink& L, const int S_total, unsigned* status,
+                                                   const int* poll_word = nullptr, int* poll_val = nullptr)
 {
     constexpr int SPB = TraceCfg<R>::SPB;
     constexpr int G = kLinkG;
@@ -180,6 +181,10 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
 #pragma unroll 1
     for (int g = 0; g < 64 / SPB; ++g) {
         const int ts = t0 + g * SPB;
+        // a band that takes its top row from memory: the progress word of the band above is looked at HALF A BLOCK before the
+        // next block needs it (one sc1 load in flight behind the steps; the block's start then finds the answer in a register
+        // instead of paying a round trip to L2 on the chain)
+        if (!LTOP && poll_word != nullptr && g == 32 / SPB) *poll_val = load_sc1_int(poll_word);
         if ((ts & (G - 1)) == 0) {
             if (LTOP) {
                 // the band above has finished step ts+G-1+64: columns ts .. ts+G-1 are in the ring; they go to lanes 0..G-1, from
@@ -271,6 +276,7 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
     int2* __restrict__ bot = J.rows + (size_t)(w + 1) * J.row_stride;
     uint8_t* tband = J.trace + (size_t)w * J.band_bytes;
     int pending = 0;                                          // SPLIT: steps whose stores have been issued but not yet published
+    int seen_above = 0;                                       // progress of the band above (another workgroup's) as last polled
     unsigned long long clk0 = 0;
     if (SPLIT && A.dbg) clk0 = __builtin_amdgcn_s_memrealtime();
 
@@ -278,7 +284,8 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
         const int c = t0 + lane;
         int na = 0;
         if (!top_lds) {
-            if (w > 0) wait_progress(&A.progress[g - 1], min(t0 + 128, S_total), A.status, lane);
+            // (seen_above: what the look-ahead poll of the previous block returned; the wait is entered only when that is not enough)
+            if (w > 0 && seen_above < min(t0 + 128, S_total)) wait_progress(&A.progress[g - 1], min(t0 + 128, S_total), A.status, lane);
             int2 nt = make_int2(0, 0);
             if (c < n) nt = (w > 0) ? load_sc1_int2(&top[c]) : top[c];
             s.th = nt.x; s.te = nt.y;
@@ -288,12 +295,13 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
         const bool steady = t0 >= 64 && t0 + 63 < n;
         const bool full = (w + 1) * 64 * R <= m;
+        const int* poll = (!top_lds && w > 0) ? &A.progress[g - 1] : nullptr;
 #define TSTA_LINKED(PRED_, FULL_)                                                                                                        \
         do {                                                                                                                             \
             if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
             else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status); \
+            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above);  \
+            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above); \
         } while (0)
         if (steady && full) TSTA_LINKED(false, true);
         else if (steady)    TSTA_LINKED(false, false);
