@@ -180,8 +180,19 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     constexpr int BAND = 64 * R;
     for (int r0 = 0; r0 < mmax; r0 += BAND) {
         const bool last = r0 + BAND >= mmax;
-        if (r0 + BAND <= mmin) pband<R, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-        else                   pband<R, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        const int rem = mmax - r0;
+        // The LAST band need not be as tall as the others: the boundary-row format does not depend on R, so the rows that are
+        // left are swept with the smallest band that covers them (50 000 rows = 24 bands of 2 048 + 848: a 1 024-row band
+        // instead of a 2 048-row one, 0.35 % instead of 2.4 % of padded rows).  Its window is a subset of the tall band's.
+        if (R >= 16 && rem <= 64 * 8) {
+            if (r0 + 64 * 8 <= mmin) pband<8, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+            else                     pband<8, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        } else if (R >= 32 && rem <= 64 * 16) {
+            if (r0 + 64 * 16 <= mmin) pband<16, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+            else                      pband<16, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        }
+        else if (r0 + BAND <= mmin) pband<R, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        else                        pband<R, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
         if (!last) wave_mem_sync();
     }
     outA = wave_max(acc.mxA);
