@@ -59,7 +59,7 @@ __device__ __forceinline__ void wait_progress(const int* word, int need, unsigne
         else __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 17)) { if (lane == 0) atomicOr(status, 1u); break; }      // far: ~14 s; near: ~0.1 s
         // once any wave has given up, nobody waits any more: the launch drains quickly
-        if ((spins & 15) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if ((spins & 255) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }
     // compiler-only barrier: the sc1 loads of the entries that follow (other addresses, relaxed) must not be hoisted above
     // the final poll.  The hardware ordering comes from the s_waitcnt on the poll's result, which the loop exit depends on.
