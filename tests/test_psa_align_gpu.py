@@ -120,6 +120,19 @@ def test_single_launch_fill_vs_tile_pipeline(eng):
                 eng.set_option("trace_persistent", 0); got0 = eng.psa_align(a, b)
                 o = util.oracle_align(a, b)
                 assert got1 == got2 == got3 == got4 == got0 == (o[0], o[2], o[3]), (R, l1, l2)
+        # the split form has two code paths for the substitution term: a byte table for pure-ACGT pairs, compare + select for any
+        # other byte (lower case, N, ...): the same pair through both, and a pair that only the second can take
+        eng.set_option("trace_rows", 0); eng.set_option("trace_split", 2)
+        a = util.random_dna(4711, 5000); b = util.mutate(a, 4712, 0.07)
+        o = util.oracle_align(a, b)
+        assert eng.psa_align(a, b) == (o[0], o[2], o[3])
+        eng.set_option("psa_perm", 0)
+        assert eng.psa_align(a, b) == (o[0], o[2], o[3])
+        eng.set_option("psa_perm", 1)
+        a2 = a.copy(); a2[::97] = ord("N"); a2[5::211] = ord("a"); b2 = b.copy(); b2[3::89] = ord("N"); b2[7::301] = ord("t")
+        o = util.oracle_align(a2, b2)
+        assert eng.psa_align(a2, b2) == (o[0], o[2], o[3])
+        eng.set_option("trace_split", 1)
         eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 0)
         pairs = []
         for i in range(48):
@@ -133,7 +146,7 @@ def test_single_launch_fill_vs_tile_pipeline(eng):
             assert (ms, ra, rb) == (o[0], o[2], o[3])
     finally:
         eng.set_option("trace_rows", 0); eng.set_option("trace_persistent", 1); eng.set_option("trace_packed", 1); eng.set_option("trace_lds", 1)
-        eng.set_option("trace_split", 1)
+        eng.set_option("trace_split", 1); eng.set_option("psa_perm", 1)
 
 
 def test_rows_per_lane_4_variant(eng):

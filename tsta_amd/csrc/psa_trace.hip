@@ -61,7 +61,10 @@ struct TLane {
 // bracket is built with three v_lshl_add_u32 (it may be negative), shifted into its byte with a fourth, and the +20
 // of all four bytes of a dword is added once (0x14141414) by the caller — integer arithmetic is linear, borrows
 // between bytes cancel.
-template <int R, bool PRED, bool TRACE, bool FULL = false>   // FULL: every row of the band is a real row (no mask on the running max)
+// ACGT (split form, pure-ACGT pairs): the match / mismatch term is ONE v_bfe_i32 instead of compare + select — s.bch[k] holds the
+// row's four substitution scores as bytes (score against A, C, T, G at byte (ASCII >> 1) & 3), the column character travels as
+// 8 x that code, i.e. as the bit offset of its byte.  One instruction less per cell on the chain of dependent steps.
+template <int R, bool PRED, bool TRACE, bool FULL = false, bool ACGT = false>   // FULL: every row of the band is a real row (no mask on the running max)
 __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int lane, const int n, const int nvalid,
                                            const int M, const int X, const int E, const int O, int (&tb)[(R + 3) / 4])
 {
@@ -79,7 +82,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     for (int k = 0; k < R; ++k) {
         const int e = eu + E;
         const int f = s.fb[k] + E;
-        const int dg = d + (s.cch == s.bch[k] ? M : X);
+        const int dg = d + (ACGT ? __builtin_amdgcn_sbfe(s.bch[k], s.cch, 8) : (s.cch == s.bch[k] ? M : X));
         h = max3i(dg, e, f);
         const int g = h + O;
         if (TRACE) {
@@ -110,7 +113,7 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
     if (PRED) s.hd = act ? hu : s.hd; else s.hd = hu;
 }
 
-template <int R, bool PRED, bool TRACE, bool WT = false, bool FULL = false>   // (WT unused: kept so call sites read the same)
+template <int R, bool PRED, bool TRACE, bool WT = false, bool FULL = false, bool ACGT = false>   // (WT unused: kept so call sites read the same)
 __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                             const int M, const int X, const int E, const int O, uint4* __restrict__ tq)
 {
@@ -124,7 +127,7 @@ __device__ __forceinline__ void trace_block(TLane<R>& s, const int t0, const int
             int tb[(R + 3) / 4];
 #pragma unroll
             for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
-            trace_step<R, PRED, TRACE, FULL>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
+            trace_step<R, PRED, TRACE, FULL, ACGT>(s, t0 + g * SPB + q, lane, n, nvalid, M, X, E, O, tb);
             if constexpr (!TRACE) { (void)acc; }
             else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
@@ -169,7 +172,7 @@ __device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* statu
 
 constexpr int kLinkG = 16;                                // columns per LDS hand-off (16 / R steps make one trace group: G is a multiple of it)
 
-template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true>
+template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true, bool ACGT = false>
 __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                                    const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
                                                    const LdsLink& L, const int S_total, unsigned* status,
@@ -201,7 +204,7 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
             int tb[(R + 3) / 4];
 #pragma unroll
             for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
-            trace_step<R, PRED, TRACE, FULL>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
+            trace_step<R, PRED, TRACE, FULL, ACGT>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
             if constexpr (!TRACE) { (void)acc; }
             else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
@@ -238,7 +241,17 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
 // C steps (`ckpt`); `eprog[band]` says how far both have been published.  That publication is deferred by one 64-step block:
 // the wave drains its stores (s_waitcnt vmcnt(0)) before the stores of the current block are issued, when those of the
 // previous block have long landed, so the drain costs nothing on the chain.
-template <int R, bool SPLIT>
+// the four substitution scores of a row character as bytes, at byte (ASCII >> 1) & 3 the score against that character (ACGT variants)
+__device__ __forceinline__ int acgt_score_table(int row_char, int M, int X)
+{
+    const unsigned xs = (unsigned)X & 0xffu, ms = (unsigned)M & 0xffu;
+    unsigned t = xs * 0x01010101u;
+    if (row_char < 0x100) { const unsigned sh = 8u * (((unsigned)row_char >> 1) & 3u); t = (t & ~(0xffu << sh)) | (ms << sh); }
+    return (int)t;
+}
+__device__ __forceinline__ int acgt_shift(int col_char) { return (int)(8u * (((unsigned)col_char >> 1) & 3u)); }
+
+template <int R, bool SPLIT, bool ACGT = false>
 __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, const int wave, const int lane, int2 (*ring)[kRing + 64], int* done)
 {
     constexpr int NS = TraceCfg<R>::NS;
@@ -257,6 +270,10 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
     TLane<R> s;
 #pragma unroll
     for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < m) ? (int)seq_b[i0 + k] : 0x100;
+    if (ACGT) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) s.bch[k] = acgt_score_table(s.bch[k], M, X);
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int hk = hcol0t(i0 + 1 + k, E, O);
@@ -290,7 +307,7 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
             if (c < n) nt = (w > 0) ? load_sc1_int2(&top[c]) : top[c];
             s.th = nt.x; s.te = nt.y;
         }
-        if (c < n) na = seq_a[c];
+        if (c < n) na = ACGT ? acgt_shift(seq_a[c]) : (int)seq_a[c];
         s.ach = na;
         uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
         const bool steady = t0 >= 64 && t0 + 63 < n;
@@ -298,10 +315,10 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
         const int* poll = (!top_lds && w > 0) ? &A.progress[g - 1] : nullptr;
 #define TSTA_LINKED(PRED_, FULL_)                                                                                                        \
         do {                                                                                                                             \
-            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
-            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above);  \
-            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above); \
+            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
+            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above);  \
+            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above); \
         } while (0)
         if (steady && full) TSTA_LINKED(false, true);
         else if (steady)    TSTA_LINKED(false, false);
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
 // Workgroups of EIGHT waves, one per compute unit (the rings' LDS sees to that): waves 0-3 of a solver workgroup are its four
 // bands, one per SIMD; waves 4-7 — and all eight waves of the workgroups beyond the solvers — are emitters.
 constexpr int kSplitThreads = 512;
-template <int R>
+template <int R, bool ACGT>
 __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTraceArgs A)
 {
     constexpr int NS = TraceCfg<R>::NS;
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTrace
     const int wg = __builtin_amdgcn_readfirstlane(wg_s);
     if (wg < A.n_solver_wg && wave < 4) {
         __builtin_amdgcn_s_setprio(3);
-        quad_band<R, true>(A, wg, wave, lane, ring, done);
+        quad_band<R, true, ACGT>(A, wg, wave, lane, ring, done);
         return;
     }
     __builtin_amdgcn_s_setprio(0);
@@ -405,6 +422,10 @@ __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTrace
         TLane<R> s;
 #pragma unroll
         for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < J.m) ? (int)seq_b[i0 + k] : 0x100;
+        if (ACGT) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) s.bch[k] = acgt_score_table(s.bch[k], M, X);
+        }
         if (s0 == 0) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -429,13 +450,13 @@ __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTrace
             int2 nt = make_int2(0, 0); int na = 0;
             if (cc < n) {
                 nt = (w > 0) ? load_sc1_int2(&top[cc]) : top[cc];
-                na = seq_a[cc];
+                na = ACGT ? acgt_shift(seq_a[cc]) : (int)seq_a[cc];
             }
             s.th = nt.x; s.te = nt.y; s.ach = na;
             uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
             // (FULL: the running maximum is the solvers' business — nothing here reads s.mx)
-            if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, true, false, true>(s, t0, lane, n, R, M, X, E, O, tq);
-            else                         trace_block<R, true, true, false, true>(s, t0, lane, n, R, M, X, E, O, tq);
+            if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
+            else                         trace_block<R, true, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
         }
     }
 }
@@ -1028,7 +1049,12 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             int n_wg = std::max(e->n_cu, A.n_solver_wg);
             if (const char* v = getenv("TSTA_SPLIT_WG")) n_wg = std::max(A.n_solver_wg, atoi(v));     // experiments
             if (getenv("TSTA_SPLIT_NOEMIT")) A.n_tiles = 0;                                            // experiments: solvers only (no trace!)
-            if constexpr (R == 2) hipLaunchKernelGGL((psa_trace_split_kernel<2>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
+            if constexpr (R == 2) {
+                // pure-ACGT pair and byte-sized substitution scores: the match / mismatch term as a table look-up (trace_step<.., ACGT>)
+                const bool acgt = e->opt_psa_perm != 0 && p->M >= -128 && p->M <= 127 && p->X >= -128 && p->X <= 127 && pure_acgt(jobs[0]);
+                if (acgt) hipLaunchKernelGGL((psa_trace_split_kernel<2, true>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
+                else      hipLaunchKernelGGL((psa_trace_split_kernel<2, false>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
+            }
             ++launches;
         } else if (quad) {
             // one pair: bands linked through LDS inside a workgroup of four
