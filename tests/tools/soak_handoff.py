@@ -26,7 +26,8 @@ try:
     for r in range(reps):
         ms, ra, rb = eng.psa_align(x, y)
         assert ms == g["maxsorce"] and hashlib.md5(b">1\n" + ra + b"\n>2\n" + rb).hexdigest() == g["md5"], ("config 3", r)
-    print("config #3 single-launch fill: %d runs identical to the reference md5 (%.1f s, chip shared with a second engine)" % (reps, time.time() - t0), flush=True)
+    print("config #3 single-launch fill (solver bands + emitter tiles): %d runs identical to the reference md5 (%.1f s, chip shared with a second engine; "
+          "%d of them run again through the launch pipeline after an abandoned wait)" % (reps, time.time() - t0, eng.stat("single_launch_reruns")), flush=True)
 
     pairs = []
     for i in range(64):

@@ -1,3 +1,5 @@
+"""One-off: kernel ms of six config #3 alignments; with TSTA_SPLIT_CLOCK=1 the library prints when every solver band started and
+how long its sweep took (s_memrealtime), with TSTA_SPLIT_NOEMIT=1 the emitters do nothing (solver chain alone; no trace!)."""
 import sys, time, json, hashlib, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tsta_amd

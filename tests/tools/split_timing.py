@@ -1,4 +1,5 @@
-"""One-off: config #3 pair through the single-pair trace fills (split / quad / memory-linked), kernel ms + md5 check."""
+"""One-off: config #3 pair through the single-pair trace fills (split = solver bands + emitter tiles / quad), kernel ms + md5 of the
+reference's output file, then small sizes in the split form against the oracle."""
 import sys, time, json, hashlib, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
