@@ -179,7 +179,7 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
                                                    const int* poll_word = nullptr, int* poll_val = nullptr)
 {
     constexpr int SPB = TraceCfg<R>::SPB;
-    constexpr int G = kLinkG;
+    constexpr int G = kLinkG > SPB ? kLinkG : SPB;
     static_assert(G % SPB == 0 && 64 % G == 0, "hand-off every G steps");
 #pragma unroll 1
     for (int g = 0; g < 64 / SPB; ++g) {
