@@ -1,5 +1,5 @@
 # round 3 profiles: default bench line (with configs #2/#3/#4/5t), rocprofv3 kernel stats of the headline command, PMC traffic
-# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>
+# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>  (profiles/r03g_* = this script on the final build of round 3, condensed by tools/collect_profiles.py)
 set -e
 export TMPDIR=/tmp
 TAG=${1:-r03f}
