@@ -91,6 +91,9 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
  *                      waits all the same, the call is run again through the other form | 0: always one launch per tile
  *                      anti-diagonal | 2: as 1, and every call is treated as abandoned once (tests of that second run)
+ *   "poa_n_blocked"    1 (default): a sequence with a literal 'N' is filled in the blocking of the reference's AVX512 build at
+ *                      -W = "poa_ref_block" / 64 (poa_blocked.hip: what the reference computes on such input depends on it), where
+ *                      that W is 1..32 and the full int32 rows fit 16 GB | 0: the 'N' rule applied consistently (tile kernel)
  *   "test_abandon"     0 (default) | t >= 1: in every single-launch form the holder of ticket t-1 computes its work but never
  *                      publishes it, so that its dependants run into their bounded waits (tests of the second run; see
  *                      tsta_psa_score_batch_dev_status)

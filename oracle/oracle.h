@@ -82,6 +82,12 @@ typedef struct oracle_dag {
 int32_t oracle_poa_fill(const oracle_dag* g, const uint8_t* seq, int32_t n, const oracle_params* p,
                         int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore);
 
+/* The same fill in the blocking of the reference's AVX512 build at -W `W` (L = 64 W columns per block, 64 lane segments of W
+ * columns): identical to oracle_poa_fill on 'N'-free sequences; on sequences with a literal 'N' it reproduces what the
+ * reference computes at that -W (its first pass ignores the 'N' rule; see poa_oracle.c). */
+int32_t oracle_poa_fill_blocked(const oracle_dag* g, const uint8_t* seq, int32_t n, const oracle_params* p, int32_t W,
+                                int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

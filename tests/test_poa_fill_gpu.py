@@ -176,8 +176,10 @@ def test_literal_n_columns_vs_oracle(eng, cols):
     # 485-506): first / last column, runs of N, several N per tile and per lane, tiles without N next to tiles with N,
     # nodes whose base is 'N'; every trace byte, lastscore and the best sink against the oracle; the call reports
     # TSTA_WARN_REFERENCE_UNDEFINED (the reference's own output on such input depends on -W)
+    # (this is the CONSISTENT rule of the tile kernel K4, "poa_n_blocked" = 0; by default such sequences are filled in the
+    # reference's blocking: test_literal_n_in_the_reference_blocking)
     try:
-        eng.set_option("poa_cols", cols)
+        eng.set_option("poa_cols", cols); eng.set_option("poa_n_blocked", 0)
         cases = [(21, 120, 3, 300, (0, 1, 2, 299, 150, 151, 152, 153), 0), (22, 400, 6, 1000, (127, 128, 129, 255, 256, 511, 512, 999), 12),
                  (23, 70, 20, 129, (), 40), (24, 900, 4, 2000, (5,), 0), (25, 33, 2, 64, tuple(range(0, 64, 3)), 0), (26, 10, 2, 7, (6,), 0),
                  (27, 200, 5, 513, tuple(range(100, 140)), 5)]
@@ -201,7 +203,44 @@ def test_literal_n_columns_vs_oracle(eng, cols):
             assert eng.last_status == 1
             assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
     finally:
-        eng.set_option("poa_cols", 0)
+        eng.set_option("poa_cols", 0); eng.set_option("poa_n_blocked", 1)
+
+
+@pytest.mark.parametrize("W", [10, 3, 5, 16, 30, 1, 32])
+def test_literal_n_in_the_reference_blocking(eng, W):
+    # K4n (poa_blocked.hip): what the reference's AVX512 build computes at -W W on a sequence with a literal 'N' (64 lane segments of
+    # W columns per block; first pass without the rule, second pass with it) — every trace byte, lastscore and the best sink
+    # against oracle_poa_fill_blocked, which is pinned against the compiled reference (tests/test_msa_host.py)
+    try:
+        eng.set_option("poa_ref_block", 64 * W)
+        cases = [(21, 120, 3, 300, (0, 1, 2, 299, 150, 151, 152, 153), 0), (22, 400, 6, 1000, (127, 128, 129, 255, 256, 511, 512, 999), 12),
+                 (23, 70, 20, 129, (), 40), (24, 900, 4, 2000, (5,), 0), (25, 33, 2, 64, tuple(range(0, 64, 3)), 0), (26, 10, 2, 7, (6,), 0),
+                 (27, 200, 5, 513, tuple(range(100, 140)), 5), (28, 1500, 3, 1400, (639, 640, 641, 1279), 3)]
+        for seed, V, mp, n, pos, cnt in cases:
+            pred_off, pred, base, is_sink, seq = random_dag(seed, V, mp, n)
+            seq = sprinkle_n(seq, seed, pos, cnt)
+            base = base.copy(); base[::17] = ord("N")
+            for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0)):
+                got = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc))
+                assert eng.last_status == 1 and "-W %d" % W in eng.last_warning()
+                want = util.oracle_poa_fill_blocked(pred_off, pred, base, is_sink, seq, W, **sc)
+                assert got[0] == want[0], (seed, sc)
+                assert np.array_equal(got[1], want[1]), (seed, sc, np.argwhere(got[1] != want[1])[:5].tolist())
+                for name, g, w in zip(("source", "esource", "fsource"), got[2:], want[2:]):
+                    bad = np.argwhere(g != w)
+                    assert len(bad) == 0, (seed, sc, name, bad[:5].tolist(), g[tuple(bad[0])], w[tuple(bad[0])])
+            best, last, src, es, fs = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+            want_steps, want_end = util.poa_walk(pred_off, pred, is_sink, last, src, es, fs)
+            steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
+            assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
+        # a sequence without 'N' is not touched by any of this
+        pred_off, pred, base, is_sink, seq = random_dag(29, 900, 2, 700)
+        got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+        assert eng.last_status == 0 or "literal" not in eng.last_warning()
+        want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
+        assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
+    finally:
+        eng.set_option("poa_ref_block", 640)
 
 
 def test_reference_undefined_warnings(eng):

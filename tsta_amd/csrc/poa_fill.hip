@@ -774,14 +774,20 @@ void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_b
 // The three situations in which the reference's own output depends on -W / SIMD width (include/tsta_engine.h,
 // tsta_poa_fill): sets e->warn and returns TSTA_WARN_REFERENCE_UNDEFINED, else TSTA_OK.  `spread` = largest distance seen
 // on the device between two predecessor rows of one node.
-static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread)
+static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread, int max_shift = 0)
 {
     e->warn[0] = 0;
     const int64_t L = e->opt_poa_ref_block;
     const int m = std::max(std::abs(p->M), std::abs(p->X)) + std::abs(p->O) + std::abs(p->E);
     const int limit = std::max(64, 354 - 2 * m);            // tracker range 100+127+127 (c-t-simd.c:196-261) minus what one row can add
     const void* nptr = memchr(seq, 'N', (size_t)n);
-    if (nptr)
+    if (nptr && e->poa_blocked_w > 0)
+        snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
+                 "in the second pass only (c-t-simd.c:357-404 vs :461), so its own output for such input depends on -W; this result is "
+                 "what its AVX512 build computes at -W %d as long as its saturating trackers stay in range (largest shift of a row's "
+                 "scores between its two passes here: %d%s)", (long long)(static_cast<const uint8_t*>(nptr) - seq), e->poa_blocked_w, max_shift,
+                 max_shift > 60 ? "; beyond ~60 the reference's int8 offsets saturate and its output is not reproduced" : "");
+    else if (nptr)
         snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
                  "in the second pass only (c-t-simd.c:357-404 vs :461), so its own output for such input depends on -W; this result applies "
                  "the rule consistently", (long long)(static_cast<const uint8_t*>(nptr) - seq));
@@ -911,6 +917,36 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.links = 0;
 
+    // K4n (poa_blocked.hip): a sequence with a literal 'N' is filled in the reference's AVX512 blocking at -W = poa_ref_block / 64
+    // (what the reference computes there depends on it), where W <= 32 and the full int32 rows fit
+    e->poa_blocked_w = 0;
+    if (memchr(seq, 'N', (size_t)n) != nullptr && e->opt_poa_n_blocked != 0 && e->opt_poa_ref_block % 64 == 0 &&
+        e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32) {
+        PoaBlockedArgs B;
+        B.W = e->opt_poa_ref_block / 64;
+        B.nblk = (n + 64 * B.W - 1) / (64 * B.W);
+        B.hpitch = ((int64_t)n + 1 + 3) / 4 * 4;
+        const size_t rows_b = (size_t)(V + 1) * (size_t)B.hpitch * sizeof(int);
+        const size_t sync_ints = (size_t)V * B.nblk + (size_t)B.nblk + 64;
+        if (2 * rows_b <= ((size_t)16 << 30) && sync_ints * sizeof(int) <= e->scratch.bytes &&
+            e->reserve(e->rows, 2 * rows_b + 64, "hipMalloc(poa rows, blocked)", true) == TSTA_OK) {
+            B.A = A;
+            B.Hf = reinterpret_cast<int*>(e->rows.p); B.Ef = B.Hf + (size_t)(V + 1) * B.hpitch;
+            B.fc = reinterpret_cast<int*>(e->scratch.p);
+            int* d_sync = B.fc + (size_t)V * B.nblk;
+            B.ticket = reinterpret_cast<unsigned*>(d_sync); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.prog = d_sync + 64;
+            B.test_abandon = e->opt_test_abandon; B.k_fixed = -1;
+            if ((rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)B.nblk + 64) * sizeof(int), s), "hipMemsetAsync(poa blocked)"))) return rc;
+            e->timing_begin(s);
+            const bool single = e->opt_poa_dataflow != 0;       // (0: the second run after an abandoned single launch)
+            e->n_launches = launch_poa_blocked(B, single, s) + 1;
+            hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
+            e->poa_status = single ? B.status : nullptr;
+            e->poa_blocked_w = B.W;
+            return e->check(hipGetLastError(), "poa_fill (blocked) launch");
+        }
+    }
+
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
     const bool dataflow = e->opt_poa_dataflow != 0 && kc == 2 && memchr(seq, 'N', (size_t)n) == nullptr;
     e->timing_begin(s);
@@ -961,7 +997,7 @@ static int poa_fill_once(tsta_engine* eng, const tsta_params* p, const tsta_dag_
     if (rc != TSTA_OK) return rc;
     hipStream_t s = e->stream;
     e->timing_end(s);
-    int h_res[9] = {-1, 0, 0, 0, 0, 0, 0, 0, 0};
+    int h_res[10] = {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if ((rc = e->check(hipMemcpyAsync(h_res, A.best, sizeof(h_res), hipMemcpyDeviceToHost, s), "D2H best"))) return rc;
     if (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) return rc;
     if (want_trace) {
@@ -973,7 +1009,7 @@ static int poa_fill_once(tsta_engine* eng, const tsta_params* p, const tsta_dag_
     if ((rc = e->check(hipStreamSynchronize(s), "poa_fill sync"))) return rc;
     if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     if (best_sink) *best_sink = h_res[0];
-    return poa_reference_warning(e, p, V, seq, n, h_res[8]);
+    return poa_reference_warning(e, p, V, seq, n, h_res[8], h_res[9]);
 }
 
 static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
@@ -1004,7 +1040,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
-    int h_out[5] = {0, 0, 0, 0, 0};                         // walker results [0..2], best[8] = spread
+    int h_out[6] = {0, 0, 0, 0, 0, 0};                      // walker results [0..2], best[8] = spread, best[9] = largest shift (blocked fill)
     if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
@@ -1016,7 +1052,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     if (!out) return TSTA_ERR_OOM;
     if (ns && (rc = e->copy_sync(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost, "D2H steps"))) { free(out); return rc; }
     *steps = out; *n_steps = ns; *end_col = h_out[1];
-    return poa_reference_warning(e, p, V, seq, n, h_out[4]);
+    return poa_reference_warning(e, p, V, seq, n, h_out[4], h_out[5]);
 }
 
 // (see kPoaDataflowGaveUp)

@@ -50,6 +50,17 @@ struct PoaDfArgs {
 };
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s);
 
+// poa_blocked.hip: the fill in the reference's AVX512 blocking (sequences with a literal 'N')
+struct PoaBlockedArgs {
+    PoaArgs A;                           // DAG, sequence, trace arrays, lastscore, best ([9] = largest |D| seen), scoring
+    int W, nblk;                         // columns per lane segment (L = 64 W columns per block), blocks
+    int* Hf; int* Ef; int64_t hpitch;    // [(V + 1)][hpitch] absolute H(r, 0..n) / E a successor sees through r; row V = virtual init
+    int* fc;                             // [V][nblk]: F carry into block k of row r (shadow frame of the block on the left)
+    unsigned* ticket; unsigned* status; int* prog;   // blocks as tickets; prog[k] = rows block k has finished
+    int test_abandon, k_fixed;
+};
+int launch_poa_blocked(PoaBlockedArgs P, bool single, hipStream_t s);     // -> number of launches
+
 void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
 void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
 
