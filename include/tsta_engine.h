@@ -193,12 +193,14 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  * Domain: every node has < 42 predecessors (poa.h:109 / trace code space).
  *
  * What is computed is the plain int32 partial-order DP that the reference's saturating int8 machinery encodes (SURVEY
- * appendix A.2), with the column rule for a literal 'N' in `seq` applied consistently: H(r,c) := H(r,c-1) for every
- * node, trace codes by equality with that value (c-t-simd.c:461,481,485-506).  Returns TSTA_WARN_REFERENCE_UNDEFINED
- * (results valid) in the three situations where the reference's own output depends on -W / SIMD width:
- *   (1) `seq` contains a literal 'N': the reference applies the rule in its second pass only, its speculative first pass
- *       (c-t-simd.c:357-404) does not (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over
- *       -W 3/5/10/16/30; on the other 23 this library's output is byte-identical, tests/golden/msa_n_golden.json);
+ * appendix A.2).  Returns TSTA_WARN_REFERENCE_UNDEFINED (results valid) in the three situations where the reference's own
+ * output depends on -W / SIMD width:
+ *   (1) `seq` contains a literal 'N': the reference forces H(r,c) := H(r,c-1) in such columns (trace codes by equality with that
+ *       value, c-t-simd.c:461,481,485-506) in its second pass only, its speculative first pass (c-t-simd.c:357-404) does not
+ *       (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over -W 3/5/10/16/30).  By default the fill then runs in
+ *       the blocking of the reference's AVX512 build at -W = "poa_ref_block" / 64 and reproduces what the reference computes at
+ *       that -W wherever its int8 offset trackers stay exact (179 of the 200 outputs of tests/golden/msa_n_golden.json, all of
+ *       the -W-invariant ones); option "poa_n_blocked" = 0 applies the rule consistently instead;
  *   (2) the sequence spans more L-blocks than the graph, ceil(n/L) > ceil(n_nodes/L): the first-column branch at
  *       c-t-simd.c:194 lacks the guard of :263 (L = option "poa_ref_block");
  *   (3) two predecessor rows of one node lie further apart than the reference's saturating offset tracker can

@@ -88,6 +88,8 @@ int32_t oracle_poa_fill(const oracle_dag* g, const uint8_t* seq, int32_t n, cons
 int32_t oracle_poa_fill_blocked(const oracle_dag* g, const uint8_t* seq, int32_t n, const oracle_params* p, int32_t W,
                                 int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore);
 
+int32_t oracle_poa_blocked_max_shift(int reset);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

@@ -113,6 +113,11 @@ int32_t oracle_poa_fill(const oracle_dag* g, const uint8_t* seq, int32_t n, cons
  * sums (:196-261: D = 0 again), while the F carry (row->f0, :567) keeps its shadow-frame value.
  * Restated in plain int32 (no saturation, no cutoff): equal to oracle_poa_fill on 'N'-free input for every W.
  */
+static int32_t g_blocked_max_shift = 0;
+/* largest |D| (shift of a row's scores between the reference's two passes) any call has seen since the last reset: the
+ * reference's int8 offset trackers hold about +-60 before their cutoff (c-t-simd.c:370-404) */
+int32_t oracle_poa_blocked_max_shift(int reset) { const int32_t v = g_blocked_max_shift; if (reset) g_blocked_max_shift = 0; return v; }
+
 int32_t oracle_poa_fill_blocked(const oracle_dag* g, const uint8_t* seq, int32_t n, const oracle_params* p, int32_t Wv,
                                 int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore)
 {
@@ -172,6 +177,7 @@ int32_t oracle_poa_fill_blocked(const oracle_dag* g, const uint8_t* seq, int32_t
                 if (b >= 1) {
                     const int32_t hnew = max2(H1end[b - 1], Fout[b - 1] - E);      /* :437-440 */
                     D = Hr[c_lo - 1] - hnew;
+                    if ((D < 0 ? -D : D) > g_blocked_max_shift) g_blocked_max_shift = D < 0 ? -D : D;
                     hs = hnew; fs = Fout[b - 1];
                 }
                 for (int32_t c = c_lo; c <= c_hi && c <= n; c++) {

@@ -24,5 +24,7 @@ int main(int argc, char** argv)
     if (argc < 7) return 2;
     oracle_params p = { atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) };
     if (argc > 7) g_w = atoi(argv[7]);
-    return msa_run(argv[5], argv[6], oracle_fill, NULL, &p);
+    const int rc = msa_run(argv[5], argv[6], oracle_fill, NULL, &p);
+    if (g_w > 0) fprintf(stderr, "max_shift: %d\n", (int)oracle_poa_blocked_max_shift(0));
+    return rc;
 }
