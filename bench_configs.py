@@ -63,9 +63,20 @@ def make_shard(n_pairs, length, seed, device):
     return ms(n_pairs, length, seed, device, related=0.0)
 
 
-def _trace_roofline(cells, kernel_ms, kernel):
+def _traffic(key):
+    """HBM bytes per launch of a config's dominant kernel from the committed PMC passes (profiles/traffic_configs.json, made by
+    tools/collect_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of this file; gfx950 correction applied there) or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))
+        return float(t[key]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def _trace_roofline(cells, kernel_ms, kernel, traffic_key=None):
     ach = cells / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": _traffic(traffic_key) if traffic_key else None,
             "kernel": kernel, "note": "SURVEY 8(d) trace mode: cells x 1 B of packed trace / kernel time (fill + on-device walk) against "
                                       "the 8 TB/s HBM-write roof; the binding resource is the chain of dependent steps (one pair) or "
                                       "VALU issue (batches), DESIGN.md section 4"}
@@ -99,7 +110,7 @@ def config2(eng, cores=None, reps=5, verify=True, cpu=True, seed=20252):
     out = {"config": "#2: 1024 pairs 5 kbp x 5 kbp random DNA, score only, inputs HBM-resident", "kernel_ms": t,
            "wall_ms": float(np.median(wall)), "launches": nl, "gcups": cells / t / 1e6,
            "roofline": {"bound": "hbm", "achieved": alg / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "psa_score_bands_kernel<8,true>",
+                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("psa_score_bands_kernel"), "kernel": "psa_score_bands_kernel<8,true>",
                         "valu_frac_at_4p4_ops_per_cell": cells * 4.4 / (t * 1e-3) / 7.86432e13,
                         "note": "score mode: algorithmic bytes (len_a + len_b + 4 per pair), ~0 by construction (SURVEY 8d); the kernel "
                                 "is VALU-issue-bound and, at this size, by the band pipeline's ramp (8 bands x 88 tiles per couple)"}}
@@ -181,7 +192,7 @@ def config3(eng, cores=None, verify=True, cpu=True):
            "maxsorce": ms, "alignment_len": len(ra), "kernel_ms_first": k1, "kernel_ms": k2, "launches": nl,
            "wall_ms_first": wall1 * 1e3, "wall_ms": wall2, "gcups": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e6,
            "reruns": eng.stat("single_launch_reruns"),
-           "roofline": _trace_roofline(cells, k2, "psa_trace_quad_kernel<2> + psa_walk_kernel<2,32>")}
+           "roofline": _trace_roofline(cells, k2, "psa_trace_split_kernel<2,true> (solver bands + emitter tiles) + psa_walk_kernel<2,32>", "psa_trace_split_kernel")}
     if verify:
         data = b">1\n" + ra + b"\n>2\n" + rb                 # what TSTA_psa writes (psa.c:512-516)
         ok = (ms == g["maxsorce"] and len(data) == g["size"] and hashlib.md5(data).hexdigest() == g["md5"] and
@@ -254,7 +265,7 @@ def config4(eng, cores=None, verify=True, cpu=True):
            "kernel_ms": tot_fw, "fill_kernel_ms": tot_fill, "walk_kernel_ms": tot_fw - tot_fill, "wall_ms": tot_wall,
            "gcups": tot_cells / tot_fw / 1e6, "gcups_fill": tot_cells / tot_fill / 1e6, "reruns": eng.stat("single_launch_reruns"),
            "roofline": {"bound": "hbm", "achieved": byts / (tot_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": byts / (tot_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "poa_dataflow_kernel",
+                        "frac": byts / (tot_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("poa_dataflow_kernel"), "kernel": "poa_dataflow_kernel",
                         "us_per_row": tot_fill * 1e3 / rows,
                         "note": "SURVEY 8(d) POA: 3 B/cell trace + 8 B/cell rows against 8 TB/s, and the time per graph row: the fill "
                                 "is the chain of its rows (5 000 columns are 40 workgroups wide), i.e. latency-bound, DESIGN.md section 5"}}
@@ -326,7 +337,7 @@ def config5t(eng, cores=None, n_pairs=64, L=50_000, verify=True, cpu=True):
     out = {"config": "#5 shape with traceback: %d pairs of %d x ~%d in one group (%.0f GB of packed trace in HBM)" % (n_pairs, L, L, cells / 1e9),
            "kernel_ms_first": k1, "kernel_ms": k2, "launches": nl, "wall_ms_first_with_allocation": wall1 * 1e3, "wall_ms": wall2,
            "gcups": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e6, "reruns": eng.stat("single_launch_reruns"),
-           "roofline": _trace_roofline(cells, k2, "psa_trace_packed_tile_kernel<4,true> + psa_walk_kernel<4,32>")}
+           "roofline": _trace_roofline(cells, k2, "psa_trace_packed_tile_kernel<4,true> + psa_walk_kernel<4,32>", "psa_trace_packed_tile_kernel")}
     if verify:
         for (ms, ra, rb), (a, b) in zip(res, pairs):
             la, lb = (a, b) if len(a) >= len(b) else (b, a)

@@ -89,6 +89,11 @@ int32_t oracle_poa_fill_blocked(const oracle_dag* g, const uint8_t* seq, int32_t
                                 int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore);
 
 int32_t oracle_poa_blocked_max_shift(int reset);
+/* The same fill in the reference's own number representation (int8 differences, saturating offsets with their overflow
+ * reservoirs, 64 byte lanes, both passes, the block schedule of control()): poa_oracle_i8.c.  What the compiled AVX512
+ * reference computes at -W W, including where that depends on its encoding (literal 'N', offsets beyond the cutoff). */
+int32_t oracle_poa_fill_i8(const oracle_dag* g, const uint8_t* seq, int32_t n, const oracle_params* p, int32_t W,
+                           int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore);
 
 void oracle_free(void* p);
 

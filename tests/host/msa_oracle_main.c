@@ -7,14 +7,16 @@
 #include "../../oracle/oracle.h"
 #include "../../tsta_amd/host/msa_driver.h"
 
-static int g_w = 0;      /* > 0: the fill in the reference's blocking at that -W (oracle_poa_fill_blocked) */
+static int g_w = 0;      /* > 0: the fill in the reference's blocking at that -W (oracle_poa_fill_blocked); < 0: the same in the
+                          * reference's own int8 number representation (oracle_poa_fill_i8) at -W |g_w| */
 
 static int oracle_fill(void* vctx, int n_nodes, const int32_t* pred_off, const int32_t* pred, const uint8_t* base,
                        const uint8_t* is_sink, const uint8_t* seq, int32_t n, int8_t* source, int8_t* esource,
                        int8_t* fsource, int32_t* lastscore)
 {
     oracle_dag dag = { n_nodes, pred_off, pred, base, is_sink };
-    if (g_w > 0) oracle_poa_fill_blocked(&dag, seq, n, (const oracle_params*)vctx, g_w, source, esource, fsource, lastscore);
+    if (g_w < 0) oracle_poa_fill_i8(&dag, seq, n, (const oracle_params*)vctx, -g_w, source, esource, fsource, lastscore);
+    else if (g_w > 0) oracle_poa_fill_blocked(&dag, seq, n, (const oracle_params*)vctx, g_w, source, esource, fsource, lastscore);
     else         oracle_poa_fill(&dag, seq, n, (const oracle_params*)vctx, source, esource, fsource, lastscore);
     return 0;
 }

@@ -24,7 +24,7 @@ def oracle_driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("msa") / "msa_oracle_main")
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-o", exe, os.path.join(util.ROOT, "tests", "host", "msa_oracle_main.c"),
                            os.path.join(HOST, "msa_driver.c"), os.path.join(HOST, "poa_graph.c"), os.path.join(HOST, "fasta.c"),
-                           os.path.join(util.ORACLE_DIR, "poa_oracle.c"), "-lz", "-lpthread"])
+                           os.path.join(util.ORACLE_DIR, "poa_oracle.c"), os.path.join(util.ORACLE_DIR, "poa_oracle_i8.c"), "-lz", "-lpthread"])
     return exe
 
 
@@ -180,6 +180,28 @@ def test_blocked_fill_reproduces_the_w_dependence(oracle_driver, tmp_path):
     # exact there once an 'N'-shifted row is involved, and in some runs the cutoff then latches (a sink's lastsorce of -4395 where
     # scores are bounded by +-1400); plain integers do not follow that
     assert total == 200 and ok >= 179 and ok_default >= 36 and dependent_fully_explained >= 6, (ok, ok_default, dependent_fully_explained)
+
+
+# ---- and WHAT it is exactly: oracle_poa_fill_i8 (oracle/poa_oracle_i8.c) states the fill in the reference's own number
+# representation (int8 differences, saturating offsets with their reservoirs, the cutoff, both passes, control()'s block schedule).
+def test_i8_fill_reproduces_every_n_output(oracle_driver, tmp_path):
+    from tests.golden.make_msa_n_golden import WS
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    sc = dict(M=2, X=-5, E=-2, O=-4)
+    bad = []
+    for c in N_GOLDEN:
+        write_multi_fasta(fa, n_case_seqs(c))
+        by_w = c["md5_by_w"] if isinstance(c["md5_by_w"], dict) else eval(c["md5_by_w"])
+        bad += [(c["seed"], w) for w in WS if _run_blocked(oracle_driver, fa, out, sc, -w) != by_w[str(w)]]
+    assert not bad, bad                                          # all 40 inputs x 5 values of -W: the compiled reference's bytes
+
+
+@pytest.mark.parametrize("idx", [i for i in range(len(GOLDEN)) if i % 3 == 1 or GOLDEN[i]["kind"] == "example"])
+def test_i8_fill_equals_plain_fill_without_n(oracle_driver, tmp_path, idx):
+    c = GOLDEN[idx]
+    out = str(tmp_path / "out.txt")
+    for w in (10, 5):
+        assert _run_blocked(oracle_driver, input_path(c, tmp_path), out, c["scoring"], -w) == c["md5"], w
 
 
 @pytest.mark.gpu

@@ -50,3 +50,21 @@ def test_readme_known_answers():
         assert len(z["base"]) == V
         sinks = np.nonzero(z["is_sink"])[0]
         assert z["lastsorce"][sinks].max() == ls
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[4:-4] for p in FIXTURES])
+def test_poa_oracle_i8_matches_reference_dump(path):
+    # the restatement in the reference's own int8 representation (oracle/poa_oracle_i8.c) against the same dumps; the dumps were
+    # made at the default -W 10 (make_poa_golden.py)
+    z, sc = load(path)
+    best, last, src, es, fs = util.oracle_poa_fill_i8(z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"], 10, **sc)
+    check_against_fixture(z, best, last, src, es, fs)
+
+
+def test_poa_oracle_i8_equals_plain_oracle_at_other_w():
+    z, sc = load([f for f in FIXTURES if f.endswith("poa_medium_step2.npz")][0])
+    args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+    want = util.oracle_poa_fill(*args, **sc)
+    for w in (1, 3, 16):                                         # (at -W 32 the reference's int8 lane sums wrap on this input: test_msa_host.py)
+        got = util.oracle_poa_fill_i8(*args, w, **sc)
+        assert got[0] == want[0] and all(np.array_equal(g, x) for g, x in zip(got[1:], want[1:])), w

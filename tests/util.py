@@ -230,6 +230,25 @@ def oracle_poa_fill_blocked(pred_off, pred, base, is_sink, seq, W, M=2, X=-5, E=
     return int(best), last, src, es, fs
 
 
+def oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W, M=2, X=-5, E=-2, O=-4):
+    """The fill in the reference's own int8 number representation and block schedule at -W W (oracle/poa_oracle_i8.c)."""
+    pred_off = np.ascontiguousarray(pred_off, dtype=np.int32)
+    pred = np.ascontiguousarray(pred if len(pred) else np.zeros(1), dtype=np.int32)
+    base = np.ascontiguousarray(base, dtype=np.uint8); is_sink = np.ascontiguousarray(is_sink, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    V, n = len(base), len(seq)
+    g = OracleDag(V, _ptr(pred_off).value, _ptr(pred).value, _ptr(base).value, _ptr(is_sink).value)
+    p = OracleParams(M, X, E, O)
+    last = np.zeros(V, dtype=np.int32)
+    src = np.zeros((V, n), dtype=np.int8); es = np.zeros((V, n), dtype=np.int8); fs = np.zeros((V, n), dtype=np.int8)
+    lib = oracle()
+    lib.oracle_poa_fill_i8.restype = C.c_int32
+    lib.oracle_poa_fill_i8.argtypes = [C.POINTER(OracleDag), C.c_void_p, C.c_int32, C.POINTER(OracleParams), C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    best = lib.oracle_poa_fill_i8(C.byref(g), _ptr(seq), n, C.byref(p), int(W), _ptr(src), _ptr(es), _ptr(fs), _ptr(last))
+    return int(best), last, src, es, fs
+
+
 # ------------------------------------------------------------------------------ reference binaries
 
 def ref_available(name="TSTA_psa"):

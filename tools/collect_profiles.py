@@ -55,6 +55,31 @@ if fe and wr:
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                     "--no-cpu-baseline --no-generic (separate passes)"}
     json.dump(t, open(os.path.join(out, "traffic_psa_score.json"), "w"), indent=1)
+# HBM traffic of the configs' dominant kernels (bench_configs.py 2 3 4 5t under separate FETCH_SIZE / WRITE_SIZE passes):
+# profiles/traffic_configs.json, read by bench_configs.py for roofline.traffic
+def pmc_by_kernel(sub, counter):
+    f = sorted(glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    acc = {}
+    for r in csv.DictReader(open(f[-1])) if f else []:
+        if r["Counter_Name"] == counter:
+            acc.setdefault(r["Kernel_Name"].split("<")[0].split("(")[0].replace("void ", "").replace("tsta::", ""), []).append(float(r["Counter_Value"]) * 1024)
+    return acc
+
+
+cf, cw = pmc_by_kernel("prof_cfg_fetch", "FETCH_SIZE"), pmc_by_kernel("prof_cfg_write", "WRITE_SIZE")
+if cf and cw:
+    tc = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench_configs.py 2 3 4 5t; "
+                  "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, "
+                  "mean over the launches of that kernel in the run; poa_dataflow_kernel: x 4 = one set of the README example's four "
+                  "fills (the unit configs['4'].roofline.achieved is quoted on)"}
+    for k in sorted(set(cf) & set(cw)):
+        if not any(x in k for x in ("psa_", "poa_")):
+            continue
+        fb, wb = sum(cf[k]) / len(cf[k]), sum(cw[k]) / len(cw[k])
+        mult = 4 if k == "poa_dataflow_kernel" else 1
+        tc[k] = {"launches_seen": len(cf[k]), "FETCH_SIZE_bytes_raw_mean": fb, "WRITE_SIZE_bytes_mean": wb,
+                 "hbm_bytes_per_launch": mult * (2 * fb + wb)}
+    json.dump(tc, open(os.path.join(out, "traffic_configs.json"), "w"), indent=1)
 # SQ counters of the headline kernel (VALU issue evidence): profiles/valu_psa_score.json, read by bench.py
 def sq(sub, kernel):
     f = sorted(glob.glob(os.path.join(base, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)

@@ -20,3 +20,6 @@ TSTA_BENCH_NO_CPU=1 timeout -k 10 400 python bench_configs.py 2 3 4 5t 5m 5s 5h 
 echo "configs done"; cut -c1-160 $O/configs.jsonl
 TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg -- python3 bench_configs.py 2 3 4 5t 5m > $O/configs_prof.jsonl 2> $O/prof_cfg.err
 echo "config stats done"
+TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_fetch -- python3 bench_configs.py 2 3 4 5t > $O/configs_fetch.jsonl 2> $O/prof_cfg_fetch.err
+TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_write -- python3 bench_configs.py 2 3 4 5t > $O/configs_write.jsonl 2> $O/prof_cfg_write.err
+echo "config traffic done"
