@@ -91,9 +91,12 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
  *                      waits all the same, the call is run again through the other form | 0: always one launch per tile
  *                      anti-diagonal | 2: as 1, and every call is treated as abandoned once (tests of that second run)
- *   "poa_n_blocked"    1 (default): a sequence with a literal 'N' is filled in the blocking of the reference's AVX512 build at
- *                      -W = "poa_ref_block" / 64 (poa_blocked.hip: what the reference computes on such input depends on it), where
- *                      that W is 1..32 and the full int32 rows fit 16 GB | 0: the 'N' rule applied consistently (tile kernel)
+ *   "poa_ref_arith"    1 (default): a fill on which the reference's output is a property of its int8 arithmetic and blocking (see
+ *                      tsta_poa_fill: a literal 'N', a sequence spanning more blocks than the graph, long padding at large -W,
+ *                      predecessor rows beyond its trackers) runs in that arithmetic, in the blocking of the reference's AVX512
+ *                      build at -W = "poa_ref_block" / 64 (poa_ref8.hip), and returns the reference's bytes; needs that W in
+ *                      1..32 and (largest in-degree) x (2 ceil(W/4) + 3) x 256 B of LDS <= 152 KB | 0: never (plain DP + warning) |
+ *                      2: every fill (tests).  "poa_n_blocked" is accepted as an older name of the same option
  *   "test_abandon"     0 (default) | t >= 1: in every single-launch form the holder of ticket t-1 computes its work but never
  *                      publishes it, so that its dependants run into their bounded waits (tests of the second run; see
  *                      tsta_psa_score_batch_dev_status)
@@ -193,18 +196,22 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  * Domain: every node has < 42 predecessors (poa.h:109 / trace code space).
  *
  * What is computed is the plain int32 partial-order DP that the reference's saturating int8 machinery encodes (SURVEY
- * appendix A.2).  Returns TSTA_WARN_REFERENCE_UNDEFINED (results valid) in the three situations where the reference's own
- * output depends on -W / SIMD width:
+ * appendix A.2) — except in the situations where the reference's own output is NOT that DP but a property of its encoding
+ * (and therefore of -W / the SIMD width of the build):
  *   (1) `seq` contains a literal 'N': the reference forces H(r,c) := H(r,c-1) in such columns (trace codes by equality with that
  *       value, c-t-simd.c:461,481,485-506) in its second pass only, its speculative first pass (c-t-simd.c:357-404) does not
- *       (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over -W 3/5/10/16/30).  By default the fill then runs in
- *       the blocking of the reference's AVX512 build at -W = "poa_ref_block" / 64 and reproduces what the reference computes at
- *       that -W wherever its int8 offset trackers stay exact (179 of the 200 outputs of tests/golden/msa_n_golden.json, all of
- *       the -W-invariant ones); option "poa_n_blocked" = 0 applies the rule consistently instead;
+ *       (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over -W 3/5/10/16/30);
  *   (2) the sequence spans more L-blocks than the graph, ceil(n/L) > ceil(n_nodes/L): the first-column branch at
  *       c-t-simd.c:194 lacks the guard of :263 (L = option "poa_ref_block");
  *   (3) two predecessor rows of one node lie further apart than the reference's saturating offset tracker can
- *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device).
+ *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device);
+ *   (4) the last block is padded and W |E| + |O| >= 56: one byte lane's W padding columns ('N', readseq) shift a row beyond the
+ *       trackers' cutoff between the two passes (measured: -W 32 at the default scoring).
+ * There the fill runs — (1), (2), (4) at once, (3) as a second run after the plain fill has seen the distance — in the reference's
+ * own arithmetic and in the blocking of its AVX512 build at -W = "poa_ref_block" / 64 (option "poa_ref_arith"), and the result is
+ * what that build prints, byte for byte (all 200 outputs of tests/golden/msa_n_golden.json, all of msa_w_golden.json): status
+ * TSTA_OK.  Only where that path cannot run ("poa_ref_arith" = 0, "poa_ref_block" not 64 x 1..32, in-degree x W beyond the LDS)
+ * the call returns the plain DP ('N' rule applied consistently) with TSTA_WARN_REFERENCE_UNDEFINED and says which case it was.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct tsta_dag_csr {
     int32_t        n_nodes;

@@ -14,10 +14,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def eng():
+def _engine():
     e = tsta_amd.Engine(0)
     yield e
     e.close()
+
+
+@pytest.fixture()
+def eng(_engine):
+    # the plain kernels (K4 / K4d) against the plain oracle on arbitrary DAGs: "poa_ref_arith" = 0 keeps calls the reference's own
+    # arithmetic would answer differently (far predecessors, sequences spanning more blocks than the graph) on those kernels;
+    # the tests of the reference-arithmetic path switch it on themselves
+    _engine.set_option("poa_ref_arith", 0)
+    yield _engine
+    _engine.set_option("poa_ref_arith", 1)
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[4:-4] for p in FIXTURES])
@@ -176,10 +186,10 @@ def test_literal_n_columns_vs_oracle(eng, cols):
     # 485-506): first / last column, runs of N, several N per tile and per lane, tiles without N next to tiles with N,
     # nodes whose base is 'N'; every trace byte, lastscore and the best sink against the oracle; the call reports
     # TSTA_WARN_REFERENCE_UNDEFINED (the reference's own output on such input depends on -W)
-    # (this is the CONSISTENT rule of the tile kernel K4, "poa_n_blocked" = 0; by default such sequences are filled in the
-    # reference's blocking: test_literal_n_in_the_reference_blocking)
+    # (this is the CONSISTENT rule of the tile kernel K4, "poa_ref_arith" = 0; by default such sequences are filled in the
+    # reference's own arithmetic and blocking: test_literal_n_in_the_reference_arithmetic)
     try:
-        eng.set_option("poa_cols", cols); eng.set_option("poa_n_blocked", 0)
+        eng.set_option("poa_cols", cols); eng.set_option("poa_ref_arith", 0)
         cases = [(21, 120, 3, 300, (0, 1, 2, 299, 150, 151, 152, 153), 0), (22, 400, 6, 1000, (127, 128, 129, 255, 256, 511, 512, 999), 12),
                  (23, 70, 20, 129, (), 40), (24, 900, 4, 2000, (5,), 0), (25, 33, 2, 64, tuple(range(0, 64, 3)), 0), (26, 10, 2, 7, (6,), 0),
                  (27, 200, 5, 513, tuple(range(100, 140)), 5)]
@@ -203,16 +213,17 @@ def test_literal_n_columns_vs_oracle(eng, cols):
             assert eng.last_status == 1
             assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
     finally:
-        eng.set_option("poa_cols", 0); eng.set_option("poa_n_blocked", 1)
+        eng.set_option("poa_cols", 0)
 
 
 @pytest.mark.parametrize("W", [10, 3, 5, 16, 30, 1, 32])
-def test_literal_n_in_the_reference_blocking(eng, W):
-    # K4n (poa_blocked.hip): what the reference's AVX512 build computes at -W W on a sequence with a literal 'N' (64 lane segments of
-    # W columns per block; first pass without the rule, second pass with it) — every trace byte, lastscore and the best sink
-    # against oracle_poa_fill_blocked, which is pinned against the compiled reference (tests/test_msa_host.py)
+def test_literal_n_in_the_reference_arithmetic(eng, W):
+    # K4e (poa_ref8.hip): what the reference's AVX512 build computes at -W W on a sequence with a literal 'N' — its int8 differences,
+    # saturating offset trackers, both passes, the block schedule — every trace byte, lastscore and the best sink against
+    # oracle_poa_fill_i8, which reproduces the compiled reference on all 200 outputs of msa_n_golden.json (tests/test_msa_host.py).
+    # Random DAGs with far predecessors drive the trackers into their reservoirs and beyond the cutoff: same bytes there too.
     try:
-        eng.set_option("poa_ref_block", 64 * W)
+        eng.set_option("poa_ref_block", 64 * W); eng.set_option("poa_ref_arith", 1)
         cases = [(21, 120, 3, 300, (0, 1, 2, 299, 150, 151, 152, 153), 0), (22, 400, 6, 1000, (127, 128, 129, 255, 256, 511, 512, 999), 12),
                  (23, 70, 20, 129, (), 40), (24, 900, 4, 2000, (5,), 0), (25, 33, 2, 64, tuple(range(0, 64, 3)), 0), (26, 10, 2, 7, (6,), 0),
                  (27, 200, 5, 513, tuple(range(100, 140)), 5), (28, 1500, 3, 1400, (639, 640, 641, 1279), 3)]
@@ -222,25 +233,48 @@ def test_literal_n_in_the_reference_blocking(eng, W):
             base = base.copy(); base[::17] = ord("N")
             for sc in (dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0)):
                 got = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc))
-                assert eng.last_status == 1 and "-W %d" % W in eng.last_warning()
-                want = util.oracle_poa_fill_blocked(pred_off, pred, base, is_sink, seq, W, **sc)
+                assert eng.last_status == 0 and eng.last_warning() == "", (seed, eng.last_warning())
+                want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W, **sc)
                 assert got[0] == want[0], (seed, sc)
                 assert np.array_equal(got[1], want[1]), (seed, sc, np.argwhere(got[1] != want[1])[:5].tolist())
                 for name, g, w in zip(("source", "esource", "fsource"), got[2:], want[2:]):
                     bad = np.argwhere(g != w)
-                    assert len(bad) == 0, (seed, sc, name, bad[:5].tolist(), g[tuple(bad[0])], w[tuple(bad[0])])
+                    assert len(bad) == 0, (seed, sc, name, len(bad), bad[:5].tolist(), g[tuple(bad[0])], w[tuple(bad[0])])
             best, last, src, es, fs = eng.poa_fill(pred_off, pred, base, is_sink, seq)
             want_steps, want_end = util.poa_walk(pred_off, pred, is_sink, last, src, es, fs)
             steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
             assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
-        # a sequence without 'N' is not touched by any of this
+        # a sequence without 'N': status 0 always means "the reference's bytes" — the plain kernels inside the reference's domain, this
+        # kernel from -W 26 on (padding rule, poa_needs_reference_arithmetic) or after the plain fill saw predecessor rows too far apart
         pred_off, pred, base, is_sink, seq = random_dag(29, 900, 2, 700)
         got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
-        assert eng.last_status == 0 or "literal" not in eng.last_warning()
-        want = util.oracle_poa_fill(pred_off, pred, base, is_sink, seq)
+        assert eng.last_status == 0 and eng.last_warning() == ""
+        want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W)
         assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
     finally:
         eng.set_option("poa_ref_block", 640)
+
+
+@pytest.mark.parametrize("W", [10, 4, 32])
+def test_every_fill_in_the_reference_arithmetic(eng, W):
+    # "poa_ref_arith" = 2: K4e for every fill.  On the dumps of the reference itself (made at -W 10) it must give what the plain
+    # kernels give; at other -W it must follow the int8 restatement wherever that goes (at -W 32 the reference leaves the DP on the
+    # padded "medium" inputs: tests/test_msa_host.py holds the reference's own bytes for that)
+    try:
+        eng.set_option("poa_ref_block", 64 * W); eng.set_option("poa_ref_arith", 2)
+        for f in FIXTURES:
+            if "readme" in f and W != 10:
+                continue
+            z, sc = load(f)
+            args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+            got = eng.poa_fill(*args, tsta_amd.Params(**sc))
+            assert eng.last_status == 0
+            want = util.oracle_poa_fill_i8(*args, W, **sc)
+            assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:])), f
+            if W == 10:
+                check_against_fixture(z, *got)
+    finally:
+        eng.set_option("poa_ref_block", 640); eng.set_option("poa_ref_arith", 1)
 
 
 def test_reference_undefined_warnings(eng):
@@ -254,8 +288,14 @@ def test_reference_undefined_warnings(eng):
     chain_pred = np.arange(V - 1, dtype=np.int32)
     cbase = util.random_dna(32, V); csink = np.zeros(V, np.uint8); csink[-1] = 1
     seq = util.random_dna(34, 700)
+    eng.set_option("poa_ref_arith", 0)                          # (the plain kernels only: the call says what it cannot vouch for)
     eng.poa_fill(chain_off, chain_pred, cbase, csink, seq, want_trace=False)
     assert eng.last_status == 1 and "spans more blocks" in eng.last_warning()
+    eng.set_option("poa_ref_arith", 1)                          # default: such a fill runs in the reference's own arithmetic instead
+    got = eng.poa_fill(chain_off, chain_pred, cbase, csink, seq)
+    assert eng.last_status == 0 and eng.last_warning() == ""
+    want = util.oracle_poa_fill_i8(chain_off, chain_pred, cbase, csink, seq, 10)
+    assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
     eng.set_option("poa_ref_block", 1024)
     eng.poa_fill(chain_off, chain_pred, cbase, csink, seq, want_trace=False)
     assert eng.last_status == 0
@@ -274,7 +314,15 @@ def test_reference_undefined_warnings(eng):
             pred += [v - 1]
         pred_off.append(len(pred))
     is_sink = np.zeros(V, np.uint8); is_sink[-1] = 1
-    got = eng.poa_fill(np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq)
+    args = (np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq)
+    eng.set_option("poa_ref_arith", 0)
+    got = eng.poa_fill(*args)
     assert eng.last_status == 1 and "apart" in eng.last_warning()
-    want = util.oracle_poa_fill(np.array(pred_off, np.int32), np.array(pred, np.int32), base, is_sink, seq)
+    want = util.oracle_poa_fill(*args)
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and all(np.array_equal(g, w) for g, w in zip(got[2:], want[2:]))
+    # default: the spread is noticed after the plain fill, the call is run again in the reference's arithmetic
+    eng.set_option("poa_ref_arith", 1)
+    got = eng.poa_fill(*args)
+    assert eng.last_status == 0 and eng.last_warning() == ""
+    want = util.oracle_poa_fill_i8(*args, 10)
+    assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))

@@ -158,13 +158,13 @@ def test_poa_dataflow_chunk_that_never_publishes(eng):
 
 
 def test_blocked_poa_fill_block_that_never_publishes(eng):
-    # K4n (poa_blocked.hip, sequences with a literal 'N'): block 0 never publishes a row; block 1 runs into its bound, the launch
+    # K4e (poa_ref8.hip, sequences with a literal 'N'): block 0 never publishes a row; block 1 runs into its bound, the launch
     # drains, and the entry point runs the call again with one launch per block
     from tests.test_poa_fill_gpu import random_dag, sprinkle_n
     pred_off, pred, base, is_sink, seq = random_dag(31, 500, 4, 1500)
     seq = sprinkle_n(seq, 31, (700, 701), 4)
     eng.set_option("poa_ref_block", 64 * 5)                      # 320 columns per block: five blocks
-    want = util.oracle_poa_fill_blocked(pred_off, pred, base, is_sink, seq, 5)
+    want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, 5)
     got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
     assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:])) and eng.stat("single_launch_reruns") == 0
     eng.set_option("test_abandon", 1)

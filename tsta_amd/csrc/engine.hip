@@ -228,7 +228,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
     if (!strcmp(key, "trace_lds") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_lds = v; return TSTA_OK; }
     if (!strcmp(key, "poa_dataflow") && (v == 0 || v == 1 || v == 2)) { e->opt_poa_dataflow = v; return TSTA_OK; }
-    if (!strcmp(key, "poa_n_blocked") && (v == 0 || v == 1)) { e->opt_poa_n_blocked = v; return TSTA_OK; }
+    if ((!strcmp(key, "poa_ref_arith") || !strcmp(key, "poa_n_blocked")) && (v == 0 || v == 1 || v == 2)) { e->opt_poa_n_blocked = v; return TSTA_OK; }
     if (!strcmp(key, "trace_split") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_split = v; return TSTA_OK; }
     if (!strcmp(key, "test_abandon") && v >= 0) { e->opt_test_abandon = v; return TSTA_OK; }
     if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }

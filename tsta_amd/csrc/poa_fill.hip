@@ -771,23 +771,30 @@ namespace tsta {
 void launch_poa_init(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_init_kernel, dim3(std::min(64, (A.n + 256) / 256)), dim3(256), 0, s, A); }
 void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A); }
 
-// The three situations in which the reference's own output depends on -W / SIMD width (include/tsta_engine.h,
-// tsta_poa_fill): sets e->warn and returns TSTA_WARN_REFERENCE_UNDEFINED, else TSTA_OK.  `spread` = largest distance seen
-// on the device between two predecessor rows of one node.
-static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread, int max_shift = 0)
+// The situations in which the reference's own output is a property of its int8 arithmetic / blocking (include/tsta_engine.h,
+// tsta_poa_fill) and which are known before the fill: a literal 'N' (its rule lives in the second pass only, c-t-simd.c:357-404
+// vs :461); a sequence spanning more blocks than the graph (:194 unguarded); 'N' padding at a -W so large that one lane's W
+// padded columns shift a row beyond the trackers' cutoff between the two passes (measured: -W 32 at the default scoring).
+static bool poa_needs_reference_arithmetic(const Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n)
+{
+    const int64_t L = e->opt_poa_ref_block;
+    if (memchr(seq, 'N', (size_t)n) != nullptr) return true;
+    if (((int64_t)n + L - 1) / L > ((int64_t)V + L - 1) / L) return true;
+    return (n % L) != 0 && (L / 64) * std::abs(p->E) + std::abs(p->O) >= 56;
+}
+
+// After a fill: sets e->warn and returns TSTA_WARN_REFERENCE_UNDEFINED where the result is NOT what the reference prints, else
+// TSTA_OK.  `spread` = largest distance seen on the device between two predecessor rows of one node.  A fill that ran in the
+// reference's own arithmetic (poa_ref8.hip) is the reference's output at that -W: nothing to warn about.
+static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread)
 {
     e->warn[0] = 0;
+    if (e->poa_blocked_w > 0) return TSTA_OK;
     const int64_t L = e->opt_poa_ref_block;
     const int m = std::max(std::abs(p->M), std::abs(p->X)) + std::abs(p->O) + std::abs(p->E);
     const int limit = std::max(64, 354 - 2 * m);            // tracker range 100+127+127 (c-t-simd.c:196-261) minus what one row can add
     const void* nptr = memchr(seq, 'N', (size_t)n);
-    if (nptr && e->poa_blocked_w > 0)
-        snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
-                 "in the second pass only (c-t-simd.c:357-404 vs :461), so its own output for such input depends on -W; this result is "
-                 "what its AVX512 build computes at -W %d as long as its saturating trackers stay in range (largest shift of a row's "
-                 "scores between its two passes here: %d%s)", (long long)(static_cast<const uint8_t*>(nptr) - seq), e->poa_blocked_w, max_shift,
-                 max_shift > 60 ? "; beyond ~60 the reference's int8 offsets saturate and its output is not reproduced" : "");
-    else if (nptr)
+    if (nptr)
         snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
                  "in the second pass only (c-t-simd.c:357-404 vs :461), so its own output for such input depends on -W; this result applies "
                  "the rule consistently", (long long)(static_cast<const uint8_t*>(nptr) - seq));
@@ -797,6 +804,10 @@ static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const u
     else if (spread > limit)
         snprintf(e->warn, sizeof(e->warn), "two predecessor rows of one node lie %d apart (limit %d): beyond the reference's saturating offset "
                  "tracker (c-t-simd.c:196-261,370-404), its own output may deviate from the DP computed here", spread, limit);
+    else if (poa_needs_reference_arithmetic(e, p, V, seq, n))
+        snprintf(e->warn, sizeof(e->warn), "the sequence is padded by %lld columns at -W %lld: one lane's padded columns can shift a row beyond the "
+                 "cutoff of the reference's offset trackers between its two passes (c-t-simd.c:370-404), its own output may deviate from the "
+                 "DP computed here", (long long)(L - n % L), (long long)(L / 64));
     return e->warn[0] ? TSTA_WARN_REFERENCE_UNDEFINED : TSTA_OK;
 }
 
@@ -917,33 +928,46 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.links = 0;
 
-    // K4n (poa_blocked.hip): a sequence with a literal 'N' is filled in the reference's AVX512 blocking at -W = poa_ref_block / 64
-    // (what the reference computes there depends on it), where W <= 32 and the full int32 rows fit
+    // K4e (poa_ref8.hip): inputs on which the reference's output is a property of its int8 arithmetic and blocking are filled in
+    // that arithmetic, at -W = poa_ref_block / 64 (poa_needs_reference_arithmetic; option "poa_ref_arith": 0 never, 1 those
+    // inputs, 2 every fill), where W <= 32 and the per-predecessor lane state fits the LDS
     e->poa_blocked_w = 0;
-    if (memchr(seq, 'N', (size_t)n) != nullptr && e->opt_poa_n_blocked != 0 && e->opt_poa_ref_block % 64 == 0 &&
-        e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32) {
-        PoaBlockedArgs B;
-        B.W = e->opt_poa_ref_block / 64;
-        B.nblk = (n + 64 * B.W - 1) / (64 * B.W);
-        B.hpitch = ((int64_t)n + 1 + 3) / 4 * 4;
-        const size_t rows_b = (size_t)(V + 1) * (size_t)B.hpitch * sizeof(int);
-        const size_t sync_ints = (size_t)V * B.nblk + (size_t)B.nblk + 64;
-        if (2 * rows_b <= ((size_t)16 << 30) && sync_ints * sizeof(int) <= e->scratch.bytes &&
-            e->reserve(e->rows, 2 * rows_b + 64, "hipMalloc(poa rows, blocked)", true) == TSTA_OK) {
+    if (e->opt_poa_ref_block % 64 == 0 && e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32 &&
+        (e->opt_poa_n_blocked == 2 || (e->opt_poa_n_blocked == 1 && (e->force_ref8 || poa_needs_reference_arithmetic(e, p, V, seq, n))))) {
+        PoaRef8Args B;
+        B.W = e->opt_poa_ref_block / 64; B.Wq = (B.W + 3) / 4;
+        const int64_t Lb = 64 * (int64_t)B.W;
+        B.nblk = (int)((n + Lb - 1) / Lb);
+        B.nrowblk = (int)((V + Lb - 1) / Lb);
+        B.maxtag = B.nblk - 1;                                 // c-t-simd.c:987-1001 (length1 = nblk L, length2 = nrowblk L)
+        if (B.nblk >= B.nrowblk) { B.fmaxtag = B.nrowblk - 1; B.lmaxtag = B.nblk - 1; }
+        else { B.fmaxtag = B.nblk - 1; B.lmaxtag = B.nrowblk - 1; }
+        B.maxp = 1;
+        for (int r = 0; r < V; ++r) B.maxp = std::max(B.maxp, dag->pred_off[r + 1] - dag->pred_off[r]);
+        const size_t rows_b = (size_t)V * B.nblk * 2 * B.Wq * 64 * sizeof(int);
+        const size_t aux_ints = (size_t)V * (B.nblk + 1) + (size_t)V + (size_t)V * B.maxp + (size_t)B.nblk + 64 + 16;
+        if (poa_ref8_lds_bytes(B.maxp, B.Wq) <= ((size_t)152 << 10) && rows_b <= ((size_t)32 << 30) &&
+            e->reserve(e->rows, rows_b + 64, "hipMalloc(poa rows, reference arithmetic)", true) == TSTA_OK &&
+            e->reserve(e->scratch, aux_ints * sizeof(int) + 64, "hipMalloc(poa sums, reference arithmetic)", true) == TSTA_OK) {
             B.A = A;
-            B.Hf = reinterpret_cast<int*>(e->rows.p); B.Ef = B.Hf + (size_t)(V + 1) * B.hpitch;
-            B.fc = reinterpret_cast<int*>(e->scratch.p);
-            int* d_sync = B.fc + (size_t)V * B.nblk;
+            B.rows = reinterpret_cast<int*>(e->rows.p);
+            B.simple = reinterpret_cast<int*>(e->scratch.p);
+            B.first_col = B.simple + (size_t)V * (B.nblk + 1);
+            B.f0 = B.first_col + V;
+            int* d_sync = B.f0 + (size_t)V * B.maxp;
             B.ticket = reinterpret_cast<unsigned*>(d_sync); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.prog = d_sync + 64;
             B.test_abandon = e->opt_test_abandon; B.k_fixed = -1;
-            if ((rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)B.nblk + 64) * sizeof(int), s), "hipMemsetAsync(poa blocked)"))) return rc;
+            if ((rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)B.nblk + 64) * sizeof(int), s), "hipMemsetAsync(poa reference arithmetic)")) ||
+                (rc = e->check(hipMemsetAsync(A.best, 0, 16 * sizeof(int), s), "hipMemsetAsync(poa best)"))) return rc;
             e->timing_begin(s);
             const bool single = e->opt_poa_dataflow != 0;       // (0: the second run after an abandoned single launch)
-            e->n_launches = launch_poa_blocked(B, single, s) + 1;
+            const int nl = launch_poa_ref8(B, single, s);
+            if (nl < 0) { e->set_error("poa_ref8: %zu bytes of LDS refused", poa_ref8_lds_bytes(B.maxp, B.Wq)); return TSTA_ERR_INTERNAL; }
             hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
+            e->n_launches = nl + 1;
             e->poa_status = single ? B.status : nullptr;
             e->poa_blocked_w = B.W;
-            return e->check(hipGetLastError(), "poa_fill (blocked) launch");
+            return e->check(hipGetLastError(), "poa_fill (reference arithmetic) launch");
         }
     }
 
@@ -1009,7 +1033,7 @@ static int poa_fill_once(tsta_engine* eng, const tsta_params* p, const tsta_dag_
     if ((rc = e->check(hipStreamSynchronize(s), "poa_fill sync"))) return rc;
     if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     if (best_sink) *best_sink = h_res[0];
-    return poa_reference_warning(e, p, V, seq, n, h_res[8], h_res[9]);
+    return poa_reference_warning(e, p, V, seq, n, h_res[8]);
 }
 
 static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
@@ -1040,7 +1064,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
-    int h_out[6] = {0, 0, 0, 0, 0, 0};                      // walker results [0..2], best[8] = spread, best[9] = largest shift (blocked fill)
+    int h_out[6] = {0, 0, 0, 0, 0, 0};                      // walker results [0..2], best[8] = spread
     if ((rc = e->check(hipMemcpyAsync(h_out, Wk.out, sizeof(h_out), hipMemcpyDeviceToHost, s), "D2H walk out")) ||
         (lastscore && (rc = e->check(hipMemcpyAsync(lastscore, A.lastscore, (size_t)V * 4, hipMemcpyDeviceToHost, s), "D2H lastscore"))) ||
         (rc = e->check(hipStreamSynchronize(s), "poa_align sync")))
@@ -1052,7 +1076,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     if (!out) return TSTA_ERR_OOM;
     if (ns && (rc = e->copy_sync(out, Wk.steps, (size_t)ns * sizeof(tsta_poa_step), hipMemcpyDeviceToHost, "D2H steps"))) { free(out); return rc; }
     *steps = out; *n_steps = ns; *end_col = h_out[1];
-    return poa_reference_warning(e, p, V, seq, n, h_out[4], h_out[5]);
+    return poa_reference_warning(e, p, V, seq, n, h_out[4]);
 }
 
 // (see kPoaDataflowGaveUp)
@@ -1069,15 +1093,33 @@ template <class F> static int poa_with_fallback(tsta_engine* eng, F once)
     return rc == tsta::kPoaDataflowGaveUp ? TSTA_ERR_INTERNAL : rc;
 }
 
+// a fill whose predecessor rows turned out to lie further apart than the reference's trackers reach (known only afterwards) is run
+// again in the reference's own arithmetic, where that is possible
+template <class F> static int poa_with_reference_arithmetic(tsta_engine* eng, F once)
+{
+    int rc = poa_with_fallback(eng, once);
+    tsta::Engine* e = reinterpret_cast<tsta::Engine*>(eng);
+    if (rc != TSTA_WARN_REFERENCE_UNDEFINED || e->opt_poa_n_blocked != 1 || e->poa_blocked_w > 0) return rc;
+    char keep[sizeof(e->warn)];
+    memcpy(keep, e->warn, sizeof(keep));
+    e->force_ref8 = true;
+    const int rc2 = poa_with_fallback(eng, once);
+    e->force_ref8 = false;
+    if (rc2 == TSTA_OK && e->poa_blocked_w > 0) return rc2;
+    if (rc2 == TSTA_WARN_REFERENCE_UNDEFINED) return rc2;     // (the path could not run: the same result and warning again)
+    memcpy(e->warn, keep, sizeof(keep));
+    return rc2 < 0 ? rc2 : rc;
+}
+
 extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
                              int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
                              int32_t* best_sink)
 {
-    return poa_with_fallback(eng, [&] { return poa_fill_once(eng, p, dag, seq, n, source, esource, fsource, lastscore, best_sink); });
+    return poa_with_reference_arithmetic(eng, [&] { return poa_fill_once(eng, p, dag, seq, n, source, esource, fsource, lastscore, best_sink); });
 }
 
 extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
                               int32_t n, tsta_poa_step** steps, int64_t* n_steps, int32_t* end_col, int32_t* lastscore)
 {
-    return poa_with_fallback(eng, [&] { return poa_align_once(eng, p, dag, seq, n, steps, n_steps, end_col, lastscore); });
+    return poa_with_reference_arithmetic(eng, [&] { return poa_align_once(eng, p, dag, seq, n, steps, n_steps, end_col, lastscore); });
 }

@@ -50,16 +50,20 @@ struct PoaDfArgs {
 };
 int launch_poa_dataflow(Engine* e, const PoaArgs& A, int* d_work, size_t work_ints, int* d_hand, hipStream_t s);
 
-// poa_blocked.hip: the fill in the reference's AVX512 blocking (sequences with a literal 'N')
-struct PoaBlockedArgs {
-    PoaArgs A;                           // DAG, sequence, trace arrays, lastscore, best ([9] = largest |D| seen), scoring
-    int W, nblk;                         // columns per lane segment (L = 64 W columns per block), blocks
-    int* Hf; int* Ef; int64_t hpitch;    // [(V + 1)][hpitch] absolute H(r, 0..n) / E a successor sees through r; row V = virtual init
-    int* fc;                             // [V][nblk]: F carry into block k of row r (shadow frame of the block on the left)
+// poa_ref8.hip (K4e): the fill in the reference's own int8 arithmetic and AVX512 blocking (inputs on which its output depends on them)
+struct PoaRef8Args {
+    PoaArgs A;                           // DAG, sequence, trace arrays, lastscore, scoring
+    int W, Wq, nblk, maxp;               // columns per byte lane (L = 64 W per block), dwords per lane and row = ceil(W / 4), blocks, largest in-degree
+    int fmaxtag, lmaxtag, maxtag, nrowblk;   // control()'s schedule constants, in blocks (c-t-simd.c:987-1001)
+    int* rows;                           // [V][nblk][2][Wq][64]: per row and block the differences / E differences, 4 columns per dword
+    int* simple;                         // [V][nblk + 1]: running sums (simple_sorce)
+    int* first_col;                      // [V]: frist_col_sorce
+    int* f0;                             // [V][maxp]: row->f0, the F carries into the row's next block
     unsigned* ticket; unsigned* status; int* prog;   // blocks as tickets; prog[k] = rows block k has finished
     int test_abandon, k_fixed;
 };
-int launch_poa_blocked(PoaBlockedArgs P, bool single, hipStream_t s);     // -> number of launches
+size_t poa_ref8_lds_bytes(int maxp, int Wq);
+int launch_poa_ref8(PoaRef8Args P, bool single, hipStream_t s);           // -> number of launches (-1: the LDS size was refused)
 
 void launch_poa_init(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: virtual init row into slot 0
 void launch_poa_best(const PoaArgs& A, hipStream_t s);      // poa_fill.hip: best sink
