@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "../../include/tsta_engine.h"
 #include "engine.h"
@@ -118,39 +119,9 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         const int bl = rb - max(bi - P.maxtag, 0);
         const bool first_task = bi <= P.lmaxtag && bl == bj - 1;          // :194
         const bool f0_init = first_task && bi < P.nrowblk;                // :263
-        if (k > 0 && seen_left <= r) { wait_progress(&P.prog[k - 1], r + 1, P.status, lane); seen_left = r + 1; }
 
-        // ---- the block's first column: this row's offset above every predecessor (lane j = predecessor j)
-        const int pj_l = lane < np ? (is_src ? V : A.pred[poff + lane]) : -1;
-        int simple_rk = 0;
-        if (k > 0) simple_rk = load_sc1_int(&P.simple[(size_t)r * (nblk + 1) + k]);
-        {
-            int te = 0, v0 = 0, c1 = 0, c2 = 0;
-            if (is_src) {                                                  // :174-188, :227-232
-                if (k == 0) simple_rk = E + O;
-                v0 = wrap8(simple_rk - (k * L * E + (k > 0 ? O : 0)));
-                if (k == 0 && lane == 0) { store_sc1_int(&P.first_col[r], E + O); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], E + O); }
-            } else if (first_task) {                                       // :194-224
-                const int fcp = lane < np ? load_sc1_int(&P.first_col[pj_l]) : INT_MIN / 2;
-                int fc = fcp;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) fc = max(fc, __shfl_xor(fc, off, 64));
-                fc += E;
-                te = fc - fcp;
-                split_offset(te, v0, c1, c2);
-                if (k == 0) {
-                    simple_rk = fc;
-                    if (lane == 0) { store_sc1_int(&P.first_col[r], fc); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], fc); }
-                }
-            } else {                                                       // :233-261
-                te = simple_rk - (lane < np ? load_sc1_int(&P.simple[(size_t)pj_l * (nblk + 1) + k]) : 0);
-                split_offset(te, v0, c1, c2);
-            }
-            if (np == 1) { c1 = 0; c2 = 0; }                               // :339-346
-            s_v0[lane] = v0; s_c1[lane] = c1; s_c2[lane] = c2; s_te[lane] = te;
-            s_f0[lane] = f0_init ? wrap8(v0 + E + O) : (lane < np ? load_sc1_int(&P.f0[(size_t)r * maxp + lane]) : 0);     // :263-271
-        }
-        // ---- the predecessors' bytes of this block into LDS; their sums per lane (:279-288)
+        // ---- the predecessors' bytes of this block into LDS; their sums per lane (:279-288).  Rows of this block: nothing here
+        // waits for the block on the left
         for (int j = 0; j < np; ++j) {
             const int pj = is_src ? V : A.pred[poff + j];
             int sum = 0;
@@ -169,120 +140,171 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
             }
             rs[j * 64 + lane] = sum;
         }
-        // ---- what every lane starts its first pass with (:290-356)
-        if (np != 1) {
-            int m1 = INT_MAX;
-            for (int j = 0; j < np; ++j) {
-                const int x = W * E - rs[j * 64 + lane];
-                const int te = s_te[j] + scan_add(x, lane) - x;            // te_j at the start of lane b: the first column's, carried on
-                tmp[j * 64 + lane] = te; m1 = min(m1, te);                 // under the guess that this row falls by E per column
-            }
-            for (int j = 0; j < np; ++j) {
-                int v, c1, c2;
-                split_offset(tmp[j * 64 + lane] + kLogoLow - m1, v, c1, c2);
-                if (lane == 0) { v = s_v0[j]; c1 = s_c1[j]; c2 = s_c2[j]; }
-                st[j * 64 + lane] = pack4(v, c1, c2, lane == 0 ? s_f0[j] : kSmin);
-            }
-        } else st[lane] = pack4(lane == 0 ? s_v0[0] : E8, 0, 0, lane == 0 ? s_f0[0] : kSmin);
-
-        // ---- first pass (:357-404)
-        for (int i = 0; i < W; ++i) {
-            const int h = ((int)sqc[i][lane] == base) ? M : X;
-            const int q4 = (i >> 2) * 64 + lane;
-            int s1 = kSmin;
-            for (int j = 0; j < np; ++j) {
-                const int S = st[j * 64 + lane];
-                const int v = wrap8(S), f = S >> 24;
-                int t = max(max(f, h), byte_of(pe[j * Wq * 64 + q4], i));
-                t = subs8(t, v);
-                if (v > kLogoCut) t = OE8;
-                s1 = max(s1, t);
-            }
-            for (int j = 0; j < np; ++j) {
-                const int S = st[j * 64 + lane];
-                int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), f = S >> 24;
-                const int t = byte_of(pt[j * Wq * 64 + q4], i);
-                const int a = subs8(f, wrap8(t - E8));
-                const int c = adds8(v, subs8(adds8(s1, OE8), t));
-                f = max(a, c);
-                tracker_step(s1, t, v, c1, c2);
-                st[j * 64 + lane] = pack4(v, c1, c2, f);
-            }
+        // ---- the block on the left has finished this row (its running sum, its F carries); how far it is is remembered
+        if (k > 0 && seen_left <= r) {
+            int cur = __builtin_amdgcn_readfirstlane(load_sc1_int(&P.prog[k - 1]));
+            if (cur < r + 1) { wait_progress(&P.prog[k - 1], r + 1, P.status, lane); cur = r + 1; }
+            asm volatile("" ::: "memory");
+            seen_left = cur;
         }
-        // ---- lazy F across the lanes and the hand-over of every lane's end state to its right neighbour (:406-446)
-        for (int j = 0; j < np; ++j) {
-            const int S = st[j * 64 + lane];
-            const int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), ft = S >> 24;
-            const bool mid = lane >= 1 && lane <= 62;
-            const int cx = mid ? W * E - rs[j * 64 + lane] : 0;
-            const int C = scan_add(cx, lane);
-            const int te = C + scan_max(ft - C, lane);                     // te_x = max(te_{x-1} + c_x, ft_x)
-            const int ftn = mid ? min(te, kFClamp) : ft;
-            const int nv0 = max(subs8(ftn, E8), v);
-            const int f_up = __shfl_up(ftn, 1, 64), v_up = __shfl_up(nv0, 1, 64), c1_up = __shfl_up(c1, 1, 64), c2_up = __shfl_up(c2, 1, 64);
-            const int nc1 = lane ? c1_up : s_c1[j], nc2 = lane ? c2_up : s_c2[j];
-            st[j * 64 + lane] = pack4(adds8(lane ? v_up : s_v0[j], nc1), nc1, nc2, lane ? f_up : s_f0[j]);
+        // ---- the block's first column: this row's offset above every predecessor (lane j = predecessor j); all loads first
+        const int pj_l = lane < np ? (is_src ? V : A.pred[poff + lane]) : -1;
+        const bool has_p = lane < np && !is_src;
+        int simple_rk = (k > 0) ? load_sc1_int(&P.simple[(size_t)r * (nblk + 1) + k]) : 0;
+        const int fcp = (has_p && first_task) ? load_sc1_int(&P.first_col[pj_l]) : INT_MIN / 2;
+        const int spk = (has_p && !first_task) ? load_sc1_int(&P.simple[(size_t)pj_l * (nblk + 1) + k]) : 0;
+        const int f0_in = (!f0_init && lane < np) ? load_sc1_int(&P.f0[(size_t)r * maxp + lane]) : 0;
+        {
+            int te = 0, v0 = 0, c1 = 0, c2 = 0;
+            if (is_src) {                                                  // :174-188, :227-232
+                if (k == 0) simple_rk = E + O;
+                v0 = wrap8(simple_rk - (k * L * E + (k > 0 ? O : 0)));
+                if (k == 0 && lane == 0) { store_sc1_int(&P.first_col[r], E + O); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], E + O); }
+            } else if (first_task) {                                       // :194-224
+                int fc = fcp;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) fc = max(fc, __shfl_xor(fc, off, 64));
+                fc += E;
+                te = fc - fcp;
+                split_offset(te, v0, c1, c2);
+                if (k == 0) {
+                    simple_rk = fc;
+                    if (lane == 0) { store_sc1_int(&P.first_col[r], fc); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], fc); }
+                }
+            } else {                                                       // :233-261
+                te = simple_rk - spk;
+                split_offset(te, v0, c1, c2);
+            }
+            if (np == 1) { c1 = 0; c2 = 0; }                               // :339-346
+            s_v0[lane] = v0; s_c1[lane] = c1; s_c2[lane] = c2; s_te[lane] = te;
+            s_f0[lane] = f0_init ? wrap8(v0 + E + O) : f0_in;              // :263-271
         }
-        // ---- second pass (:447-565)
-        int sum = 0;
-        for (int i = 0; i < W; ++i) {
-            const int ch = sqc[i][lane];
-            const bool isn = (ch == 'N');
-            const int h = (ch == base) ? M : X;
-            const int q4 = (i >> 2) * 64 + lane;
-            int best = kSmin, eumax = kSmin;
-            for (int j = 0; j < np; ++j) {
-                const int S = st[j * 64 + lane];
-                const int v = wrap8(S), f = S >> 24;
-                const int t = byte_of(pt[j * Wq * 64 + q4], i), e = byte_of(pe[j * Wq * 64 + q4], i);
-                const int fv = subs8(f, v), eu = subs8(e, v), q = subs8(h, v), ev = subs8(e, t);
-                int c = max(max(fv, eu), q);
-                if (v > kLogoCut) c = OE8;
-                best = max(best, c); eumax = max(eumax, eu);
-                tmp[j * 64 + lane] = pack4(fv, eu, q, ev);
+        int sum = 0, f_last = 0;
+        // the three sweeps over the row; ONE: a node with a single predecessor keeps its lane state in a register
+        auto sweeps = [&](auto one_c) {
+            constexpr bool ONE = decltype(one_c)::value;
+            const int npj = ONE ? 1 : np;
+            int S1 = 0, T1 = 0;
+            auto ld = [&](int j) -> int { if constexpr (ONE) return S1; else return st[j * 64 + lane]; };
+            auto sd = [&](int j, int v) { if constexpr (ONE) S1 = v; else st[j * 64 + lane] = v; };
+            // ---- what every lane starts its first pass with (:290-356)
+            if constexpr (!ONE) {
+                int m1 = INT_MAX;
+                for (int j = 0; j < npj; ++j) {
+                    const int x = W * E - rs[j * 64 + lane];
+                    const int te = s_te[j] + scan_add(x, lane) - x;        // te_j at the start of lane b: the first column's, carried on
+                    tmp[j * 64 + lane] = te; m1 = min(m1, te);             // under the guess that this row falls by E per column
+                }
+                for (int j = 0; j < npj; ++j) {
+                    int v, c1, c2;
+                    split_offset(tmp[j * 64 + lane] + kLogoLow - m1, v, c1, c2);
+                    if (lane == 0) { v = s_v0[j]; c1 = s_c1[j]; c2 = s_c2[j]; }
+                    sd(j, pack4(v, c1, c2, lane == 0 ? s_f0[j] : kSmin));
+                }
+            } else sd(0, pack4(lane == 0 ? s_v0[0] : E8, 0, 0, lane == 0 ? s_f0[0] : kSmin));
+            // ---- first pass (:357-404)
+            for (int i = 0; i < W; ++i) {
+                const int h = ((int)sqc[i][lane] == base) ? M : X;
+                const int q4 = (i >> 2) * 64 + lane;
+                int s1 = kSmin;
+                for (int j = 0; j < npj; ++j) {
+                    const int S = ld(j);
+                    const int v = wrap8(S), f = S >> 24;
+                    int t = max(max(f, h), byte_of(pe[j * Wq * 64 + q4], i));
+                    t = subs8(t, v);
+                    if (v > kLogoCut) t = OE8;
+                    s1 = max(s1, t);
+                }
+                for (int j = 0; j < npj; ++j) {
+                    const int S = ld(j);
+                    int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), f = S >> 24;
+                    const int t = byte_of(pt[j * Wq * 64 + q4], i);
+                    const int a = subs8(f, wrap8(t - E8));
+                    const int c = adds8(v, subs8(adds8(s1, OE8), t));
+                    f = max(a, c);
+                    tracker_step(s1, t, v, c1, c2);
+                    sd(j, pack4(v, c1, c2, f));
+                }
             }
-            if (isn) best = 0;
-            sum = wrap8(sum + best);
-            const int open = adds8(best, OE8);
-            int es = 1, fs = 1, es_num = 0, m1 = 0, emax = kSmin, j_eu = -1, j_q = -1;
-            for (int j = np - 1; j >= 0; --j) {
-                const int S = st[j * 64 + lane], Tm = tmp[j * 64 + lane];
-                int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), f = S >> 24;
-                const int fv = wrap8(Tm), eu = wrap8(Tm >> 8), q = wrap8(Tm >> 16), ev = Tm >> 24;
-                const int t = byte_of(pt[j * Wq * 64 + q4], i), e = byte_of(pe[j * Wq * 64 + q4], i);
-                if (best == eu) j_eu = j;                                 // lowest j wins (:485-506)
-                if (best == q) j_q = j;
-                f = adds8(f, E8);
-                const int s1 = adds8(open, v);
-                m1 = (f == s1);
-                f = subs8(max(f, s1), t);
-                if (fv == OE8) fs = 2;
-                const int e2 = subs8(adds8(e, E8), v);
-                emax = max(emax, max(open, e2));
-                const bool m3 = (eu == eumax);
-                if (m3) { es_num = j; es = wrap8(((ev == OE8) ? 43 : 1) + es_num); if (open == e2) es = wrap8(-es); }
-                tracker_step(best, t, v, c1, c2);
-                st[j * 64 + lane] = pack4(v, c1, c2, f);
+            // ---- lazy F across the lanes and the hand-over of every lane's end state to its right neighbour (:406-446)
+            for (int j = 0; j < npj; ++j) {
+                const int S = ld(j);
+                const int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), ft = S >> 24;
+                const bool mid = lane >= 1 && lane <= 62;
+                const int cx = mid ? W * E - rs[j * 64 + lane] : 0;
+                const int C = scan_add(cx, lane);
+                const int te = C + scan_max(ft - C, lane);                 // te_x = max(te_{x-1} + c_x, ft_x)
+                const int ftn = mid ? min(te, kFClamp) : ft;
+                const int nv0 = max(subs8(ftn, E8), v);
+                const int f_up = __shfl_up(ftn, 1, 64), v_up = __shfl_up(nv0, 1, 64), c1_up = __shfl_up(c1, 1, 64), c2_up = __shfl_up(c2, 1, 64);
+                const int nc1 = lane ? c1_up : s_c1[j], nc2 = lane ? c2_up : s_c2[j];
+                sd(j, pack4(adds8(lane ? v_up : s_v0[j], nc1), nc1, nc2, lane ? f_up : s_f0[j]));
             }
-            if (m1) fs = wrap8(-fs);
-            int code = 126;
-            if (j_eu >= 0) code = j_eu;
-            if (j_q >= 0 && h == X) code = 84 + j_q;
-            if (j_q >= 0 && h == M) code = 42 + j_q;
-            reinterpret_cast<int8_t*>(&outb[0][i >> 2][lane])[i & 3] = (int8_t)best;
-            reinterpret_cast<int8_t*>(&outb[1][i >> 2][lane])[i & 3] = (int8_t)emax;
-            const int c0 = k * L + lane * W + i;
-            if (A.source && c0 < n) {
-                const size_t o = (size_t)r * A.tpitch + c0;
-                A.source[o] = (int8_t)code; A.esource[o] = (int8_t)es; A.fsource[o] = (int8_t)fs;
+            // ---- second pass (:447-565)
+            for (int i = 0; i < W; ++i) {
+                const int ch = sqc[i][lane];
+                const bool isn = (ch == 'N');
+                const int h = (ch == base) ? M : X;
+                const int q4 = (i >> 2) * 64 + lane;
+                int best = kSmin, eumax = kSmin;
+                for (int j = 0; j < npj; ++j) {
+                    const int S = ld(j);
+                    const int v = wrap8(S), f = S >> 24;
+                    const int t = byte_of(pt[j * Wq * 64 + q4], i), e = byte_of(pe[j * Wq * 64 + q4], i);
+                    const int fv = subs8(f, v), eu = subs8(e, v), q = subs8(h, v), ev = subs8(e, t);
+                    int c = max(max(fv, eu), q);
+                    if (v > kLogoCut) c = OE8;
+                    best = max(best, c); eumax = max(eumax, eu);
+                    if constexpr (ONE) T1 = pack4(fv, eu, q, ev); else tmp[j * 64 + lane] = pack4(fv, eu, q, ev);
+                }
+                if (isn) best = 0;
+                sum = wrap8(sum + best);
+                const int open = adds8(best, OE8);
+                int es = 1, fs = 1, es_num = 0, m1 = 0, emax = kSmin, j_eu = -1, j_q = -1;
+                for (int j = npj - 1; j >= 0; --j) {
+                    const int S = ld(j);
+                    int Tm;
+                    if constexpr (ONE) Tm = T1; else Tm = tmp[j * 64 + lane];
+                    int v = wrap8(S), c1 = wrap8(S >> 8), c2 = wrap8(S >> 16), f = S >> 24;
+                    const int fv = wrap8(Tm), eu = wrap8(Tm >> 8), q = wrap8(Tm >> 16), ev = Tm >> 24;
+                    const int t = byte_of(pt[j * Wq * 64 + q4], i), e = byte_of(pe[j * Wq * 64 + q4], i);
+                    if (best == eu) j_eu = j;                             // lowest j wins (:485-506)
+                    if (best == q) j_q = j;
+                    f = adds8(f, E8);
+                    const int s1 = adds8(open, v);
+                    m1 = (f == s1);
+                    f = subs8(max(f, s1), t);
+                    if (fv == OE8) fs = 2;
+                    const int e2 = subs8(adds8(e, E8), v);
+                    emax = max(emax, max(open, e2));
+                    const bool m3 = (eu == eumax);
+                    if (m3) { es_num = j; es = wrap8(((ev == OE8) ? 43 : 1) + es_num); if (open == e2) es = wrap8(-es); }
+                    tracker_step(best, t, v, c1, c2);
+                    sd(j, pack4(v, c1, c2, f));
+                }
+                if (m1) fs = wrap8(-fs);
+                int code = 126;
+                if (j_eu >= 0) code = j_eu;
+                if (j_q >= 0 && h == X) code = 84 + j_q;
+                if (j_q >= 0 && h == M) code = 42 + j_q;
+                reinterpret_cast<int8_t*>(&outb[0][i >> 2][lane])[i & 3] = (int8_t)best;
+                reinterpret_cast<int8_t*>(&outb[1][i >> 2][lane])[i & 3] = (int8_t)emax;
+                const int c0 = k * L + lane * W + i;
+                if (A.source && c0 < n) {
+                    const size_t o = (size_t)r * A.tpitch + c0;
+                    A.source[o] = (int8_t)code; A.esource[o] = (int8_t)es; A.fsource[o] = (int8_t)fs;
+                }
             }
-        }
-        // ---- what the row leaves: its bytes of this block, the F carries (row->f0, :566-567), the running sum (:568-575)
+            if constexpr (ONE) f_last = __shfl(S1 >> 24, 63, 64);         // row->f0 (:566-567): lane 63's F
+            else f_last = lane < np ? (st[lane * 64 + 63] >> 24) : 0;
+        };
+        if (np == 1) sweeps(std::true_type{}); else sweeps(std::false_type{});
+        // ---- what the row leaves: its bytes of this block, the F carries, the running sum (:568-575)
         for (int q = 0; q < Wq; ++q) {
             int* dst = P.rows + ((size_t)r * nblk + k) * blk_dw + (size_t)q * 64 + lane;
             store_sc1_int(dst, outb[0][q][lane]); store_sc1_int(dst + (size_t)Wq * 64, outb[1][q][lane]);
         }
-        if (lane < np) store_sc1_int(&P.f0[(size_t)r * maxp + lane], st[lane * 64 + 63] >> 24);
+        if (lane < np) store_sc1_int(&P.f0[(size_t)r * maxp + lane], f_last);
         int red = sum;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) red += __shfl_xor(red, off, 64);
