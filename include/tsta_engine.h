@@ -205,8 +205,8 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  *       c-t-simd.c:194 lacks the guard of :263 (L = option "poa_ref_block");
  *   (3) two predecessor rows of one node lie further apart than the reference's saturating offset tracker can
  *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device);
- *   (4) the last block is padded and W |E| + |O| >= 56: one byte lane's W padding columns ('N', readseq) shift a row beyond the
- *       trackers' cutoff between the two passes (measured: -W 32 at the default scoring).
+ *   (4) the last block is padded and W max(|E|, M) + |O| >= 60: one byte lane's W padding columns ('N', readseq) shift a row beyond
+ *       the trackers' cutoff between the two passes (measured: -W 32 at the default scoring; the bound is empirical).
  * There the fill runs — (1), (2), (4) at once, (3) as a second run after the plain fill has seen the distance — in the reference's
  * own arithmetic and in the blocking of its AVX512 build at -W = "poa_ref_block" / 64 (option "poa_ref_arith"), and the result is
  * what that build prints, byte for byte (all 200 outputs of tests/golden/msa_n_golden.json, all of msa_w_golden.json): status

@@ -245,7 +245,7 @@ def test_literal_n_in_the_reference_arithmetic(eng, W):
             steps, end_col, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
             assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
         # a sequence without 'N': status 0 always means "the reference's bytes" — the plain kernels inside the reference's domain, this
-        # kernel from -W 26 on (padding rule, poa_needs_reference_arithmetic) or after the plain fill saw predecessor rows too far apart
+        # kernel from -W 28 on (padding rule, poa_needs_reference_arithmetic) or after the plain fill saw predecessor rows too far apart
         pred_off, pred, base, is_sink, seq = random_dag(29, 900, 2, 700)
         got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
         assert eng.last_status == 0 and eng.last_warning() == ""

@@ -774,13 +774,15 @@ void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_b
 // The situations in which the reference's own output is a property of its int8 arithmetic / blocking (include/tsta_engine.h,
 // tsta_poa_fill) and which are known before the fill: a literal 'N' (its rule lives in the second pass only, c-t-simd.c:357-404
 // vs :461); a sequence spanning more blocks than the graph (:194 unguarded); 'N' padding at a -W so large that one lane's W
-// padded columns shift a row beyond the trackers' cutoff between the two passes (measured: -W 32 at the default scoring).
+// padded columns shift a row beyond the trackers' cutoff between the two passes.  That last bound is empirical: over 2 x 3 x 8
+// fixed and 60 random (graph, cut, scoring, W) combinations the int8 restatement left the plain DP first at
+// W max(|E|, M) + |O| = 68 (default scoring: -W 32); 60 is used.
 static bool poa_needs_reference_arithmetic(const Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n)
 {
     const int64_t L = e->opt_poa_ref_block;
     if (memchr(seq, 'N', (size_t)n) != nullptr) return true;
     if (((int64_t)n + L - 1) / L > ((int64_t)V + L - 1) / L) return true;
-    return (n % L) != 0 && (L / 64) * std::abs(p->E) + std::abs(p->O) >= 56;
+    return (n % L) != 0 && (L / 64) * std::max(std::abs(p->E), std::abs(p->M)) + std::abs(p->O) >= 60;
 }
 
 // After a fill: sets e->warn and returns TSTA_WARN_REFERENCE_UNDEFINED where the result is NOT what the reference prints, else
