@@ -277,6 +277,30 @@ def test_every_fill_in_the_reference_arithmetic(eng, W):
         eng.set_option("poa_ref_block", 640); eng.set_option("poa_ref_arith", 1)
 
 
+def test_reference_arithmetic_fuzz(eng):
+    # K4e against the int8 restatement on random (DAG, sequence, scoring, -W): every shape of control()'s schedule (more column
+    # blocks than row blocks and the other way round, single blocks), in-degrees up to 12, literal 'N's or none, scorings that drive
+    # the offsets into their reservoirs
+    rng = np.random.default_rng(20260403)
+    try:
+        eng.set_option("poa_ref_arith", 2)
+        for it in range(48):
+            V = int(rng.integers(1, 420)); n = int(rng.integers(1, 520)); mp = int(rng.integers(1, 13)); W = int(rng.integers(1, 33))
+            sc = dict(M=int(rng.integers(1, 7)), X=-int(rng.integers(1, 9)), E=-int(rng.integers(1, 7)), O=-int(rng.integers(0, 13)))
+            pred_off, pred, base, is_sink, seq = random_dag(1000 + it, V, mp, n)
+            if it % 3 == 0:
+                seq = sprinkle_n(seq, it, (), int(rng.integers(1, 6)))
+            eng.set_option("poa_ref_block", 64 * W)
+            got = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc))
+            if eng.last_status != 0:                             # (in-degree x W beyond the LDS: the plain DP with its warning)
+                assert mp * ((W + 3) // 4 * 2 + 3) * 256 > 152 * 1024
+                continue
+            want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W, **sc)
+            assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:])), (it, V, n, mp, W, sc)
+    finally:
+        eng.set_option("poa_ref_block", 640)
+
+
 def test_reference_undefined_warnings(eng):
     # inside the reference's domain (a dump of the reference itself): status 0, no warning
     z, sc = load(FIXTURES[0])
