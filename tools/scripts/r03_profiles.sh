@@ -1,5 +1,5 @@
 # round 3 profiles: default bench line (with configs #2/#3/#4/5t), rocprofv3 kernel stats of the headline command, PMC traffic
-# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>  (profiles/r03g_* = this script on the final build of round 3, condensed by tools/collect_profiles.py)
+# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>  (profiles/r03h_* = this script on the final build of round 3, condensed by tools/collect_profiles.py)
 set -e
 export TMPDIR=/tmp
 TAG=${1:-r03f}
@@ -20,6 +20,3 @@ TSTA_BENCH_NO_CPU=1 timeout -k 10 400 python bench_configs.py 2 3 4 5t 5m 5s 5h 
 echo "configs done"; cut -c1-160 $O/configs.jsonl
 TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg -- python3 bench_configs.py 2 3 4 5t 5m > $O/configs_prof.jsonl 2> $O/prof_cfg.err
 echo "config stats done"
-TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_fetch -- python3 bench_configs.py 2 3 4 5t > $O/configs_fetch.jsonl 2> $O/prof_cfg_fetch.err
-TSTA_BENCH_NO_CPU=1 TSTA_BENCH_NO_VERIFY=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_write -- python3 bench_configs.py 2 3 4 5t > $O/configs_write.jsonl 2> $O/prof_cfg_write.err
-echo "config traffic done"
