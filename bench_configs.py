@@ -110,10 +110,10 @@ def config2(eng, cores=None, reps=5, verify=True, cpu=True, seed=20252):
     out = {"config": "#2: 1024 pairs 5 kbp x 5 kbp random DNA, score only, inputs HBM-resident", "kernel_ms": t,
            "wall_ms": float(np.median(wall)), "launches": nl, "gcups": cells / t / 1e6,
            "roofline": {"bound": "hbm", "achieved": alg / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("psa_score_bands_kernel"), "kernel": "psa_score_bands_kernel<8,true>",
+                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("psa_score_bands_kernel"), "kernel": "psa_score_bands_kernel<16,true>",
                         "valu_frac_at_4p4_ops_per_cell": cells * 4.4 / (t * 1e-3) / 7.86432e13,
                         "note": "score mode: algorithmic bytes (len_a + len_b + 4 per pair), ~0 by construction (SURVEY 8d); the kernel "
-                                "is VALU-issue-bound and, at this size, by the band pipeline's ramp (8 bands x 88 tiles per couple)"}}
+                                "is VALU-issue-bound and, at this size, by the band pipeline's ramp (5 bands of 1 024 rows x 79 tiles per couple)"}}
     sc = scores.cpu().numpy()
     if verify:
         picks = sorted(int(x) for x in np.random.default_rng(seed).choice(P, 16, replace=False))

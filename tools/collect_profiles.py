@@ -70,14 +70,17 @@ cf, cw = pmc_by_kernel("prof_cfg_fetch", "FETCH_SIZE"), pmc_by_kernel("prof_cfg_
 if cf and cw:
     tc = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench_configs.py 2 3 4 5t; "
                   "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, "
-                  "mean over the launches of that kernel in the run; poa_dataflow_kernel: x 4 = one set of the README example's four "
+                  "median over the launches of that kernel in the run; poa_dataflow_kernel: mean x 4 = one set of the README example's four "
                   "fills (the unit configs['4'].roofline.achieved is quoted on)"}
     for k in sorted(set(cf) & set(cw)):
         if not any(x in k for x in ("psa_", "poa_")):
             continue
-        fb, wb = sum(cf[k]) / len(cf[k]), sum(cw[k]) / len(cw[k])
         mult = 4 if k == "poa_dataflow_kernel" else 1
-        tc[k] = {"launches_seen": len(cf[k]), "FETCH_SIZE_bytes_raw_mean": fb, "WRITE_SIZE_bytes_mean": wb,
+        if mult == 1:                                             # one shape per kernel: the median rejects the small warm-up launch
+            fb, wb = sorted(cf[k])[len(cf[k]) // 2], sorted(cw[k])[len(cw[k]) // 2]
+        else:                                                     # the four fills of the example, equally often: mean x 4
+            fb, wb = sum(cf[k]) / len(cf[k]), sum(cw[k]) / len(cw[k])
+        tc[k] = {"launches_seen": len(cf[k]), "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
                  "hbm_bytes_per_launch": mult * (2 * fb + wb)}
     json.dump(tc, open(os.path.join(out, "traffic_configs.json"), "w"), indent=1)
 # SQ counters of the headline kernel (VALU issue evidence): profiles/valu_psa_score.json, read by bench.py
