@@ -350,3 +350,8 @@ def test_reference_undefined_warnings(eng):
     assert eng.last_status == 0 and eng.last_warning() == ""
     want = util.oracle_poa_fill_i8(*args, 10)
     assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
+    # ... and so is the walk (tsta_poa_align: the first run's step list is dropped, the second run's returned)
+    want_steps, want_end = util.poa_walk(args[0], args[1], is_sink, want[1], want[2], want[3], want[4])
+    steps, end_col, _ = eng.poa_align(*args)
+    assert eng.last_status == 0
+    assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)

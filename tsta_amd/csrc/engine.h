@@ -31,6 +31,7 @@ struct Engine {
     bool      no_single_launch = false;   // set around such a second run
     int       single_launch_reruns = 0;   // calls that were run again through the launch pipeline after an abandoned single launch
     int       poa_blocked_w = 0;      // > 0: the last POA fill ran in the reference's own arithmetic and blocking at that -W (poa_ref8.hip)
+    bool      ref8_feasible = false;  // the last POA fill could have run through poa_ref8.hip (-W in range, LDS, memory)
     bool      force_ref8 = false;     // transient: run the next POA fill through poa_ref8.hip if it can be (second run after a spread beyond the trackers)
     unsigned* poa_status = nullptr;   // device word the last POA fill's waits report into (dataflow form), or null
     int align_calls = 0;   // tsta_psa_align_batch calls so far (its workspace cap grows with them)

@@ -934,8 +934,8 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     // that arithmetic, at -W = poa_ref_block / 64 (poa_needs_reference_arithmetic; option "poa_ref_arith": 0 never, 1 those
     // inputs, 2 every fill), where W <= 32 and the per-predecessor lane state fits the LDS
     e->poa_blocked_w = 0;
-    if (e->opt_poa_ref_block % 64 == 0 && e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32 &&
-        (e->opt_poa_n_blocked == 2 || (e->opt_poa_n_blocked == 1 && (e->force_ref8 || poa_needs_reference_arithmetic(e, p, V, seq, n))))) {
+    e->ref8_feasible = false;
+    if (e->opt_poa_n_blocked != 0 && e->opt_poa_ref_block % 64 == 0 && e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32) {
         PoaRef8Args B;
         B.W = e->opt_poa_ref_block / 64; B.Wq = (B.W + 3) / 4;
         const int64_t Lb = 64 * (int64_t)B.W;
@@ -948,9 +948,14 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
         for (int r = 0; r < V; ++r) B.maxp = std::max(B.maxp, dag->pred_off[r + 1] - dag->pred_off[r]);
         const size_t rows_b = (size_t)V * B.nblk * 2 * B.Wq * 64 * sizeof(int);
         const size_t aux_ints = (size_t)V * (B.nblk + 1) + (size_t)V + (size_t)V * B.maxp + (size_t)B.nblk + 64 + 16;
-        if (poa_ref8_lds_bytes(B.maxp, B.Wq) <= ((size_t)152 << 10) && rows_b <= ((size_t)32 << 30) &&
-            e->reserve(e->rows, rows_b + 64, "hipMalloc(poa rows, reference arithmetic)", true) == TSTA_OK &&
-            e->reserve(e->scratch, aux_ints * sizeof(int) + 64, "hipMalloc(poa sums, reference arithmetic)", true) == TSTA_OK) {
+        e->ref8_feasible = poa_ref8_lds_bytes(B.maxp, B.Wq) <= ((size_t)152 << 10) && rows_b <= ((size_t)32 << 30);
+        if (e->ref8_feasible &&
+            (e->opt_poa_n_blocked == 2 || e->force_ref8 || poa_needs_reference_arithmetic(e, p, V, seq, n))) {
+            // (a failed allocation is an error, not a reason to go on with the other kernels: their row pointers above may
+            // refer to a buffer this reservation has just replaced)
+            if ((rc = e->reserve(e->rows, rows_b + 64, "hipMalloc(poa rows, reference arithmetic)", true)) ||
+                (rc = e->reserve(e->scratch, aux_ints * sizeof(int) + 64, "hipMalloc(poa sums, reference arithmetic)", true)))
+                return rc;
             B.A = A;
             B.rows = reinterpret_cast<int*>(e->rows.p);
             B.simple = reinterpret_cast<int*>(e->scratch.p);
@@ -1097,13 +1102,14 @@ template <class F> static int poa_with_fallback(tsta_engine* eng, F once)
 
 // a fill whose predecessor rows turned out to lie further apart than the reference's trackers reach (known only afterwards) is run
 // again in the reference's own arithmetic, where that is possible
-template <class F> static int poa_with_reference_arithmetic(tsta_engine* eng, F once)
+template <class F, class D> static int poa_with_reference_arithmetic(tsta_engine* eng, F once, D discard)
 {
     int rc = poa_with_fallback(eng, once);
     tsta::Engine* e = reinterpret_cast<tsta::Engine*>(eng);
-    if (rc != TSTA_WARN_REFERENCE_UNDEFINED || e->opt_poa_n_blocked != 1 || e->poa_blocked_w > 0) return rc;
+    if (rc != TSTA_WARN_REFERENCE_UNDEFINED || e->opt_poa_n_blocked != 1 || e->poa_blocked_w > 0 || !e->ref8_feasible) return rc;
     char keep[sizeof(e->warn)];
     memcpy(keep, e->warn, sizeof(keep));
+    discard();                                                // (what the first run allocated for the caller)
     e->force_ref8 = true;
     const int rc2 = poa_with_fallback(eng, once);
     e->force_ref8 = false;
@@ -1117,11 +1123,12 @@ extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_
                              int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
                              int32_t* best_sink)
 {
-    return poa_with_reference_arithmetic(eng, [&] { return poa_fill_once(eng, p, dag, seq, n, source, esource, fsource, lastscore, best_sink); });
+    return poa_with_reference_arithmetic(eng, [&] { return poa_fill_once(eng, p, dag, seq, n, source, esource, fsource, lastscore, best_sink); }, [] {});
 }
 
 extern "C" int tsta_poa_align(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
                               int32_t n, tsta_poa_step** steps, int64_t* n_steps, int32_t* end_col, int32_t* lastscore)
 {
-    return poa_with_reference_arithmetic(eng, [&] { return poa_align_once(eng, p, dag, seq, n, steps, n_steps, end_col, lastscore); });
+    return poa_with_reference_arithmetic(eng, [&] { return poa_align_once(eng, p, dag, seq, n, steps, n_steps, end_col, lastscore); },
+                                         [&] { if (steps && *steps) { free(*steps); *steps = nullptr; } });
 }
