@@ -599,39 +599,58 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                     }
                 }
                 if (forced < 0) {
-                    // ---- consecutive diagonal steps inside the window: the steps are collected in lanes (v_writelane) and stored
-                    // 64 at a time; a step's peek is known one step later, so its code word is written then
-                    int bufN = 0, bufC = 0, bufW = 0;
-                    int k = 0, base_idx = ns, prev_code = 0, ones = 0;
-                    if (pend) { wlane(bufN, pend_node, 0); wlane(bufC, pend_col, 0); prev_code = pend_code; base_idx = pend_idx; k = 1; pend = false; }
+                    // ---- consecutive diagonal steps inside the window.  The chain itself is scalar and dependent (the link of a cell
+                    // says where the next one is), so it only RECORDS: one word per step (code | link distance << 8) into lane k.
+                    // Nodes, columns and peeks of all recorded steps are worked out afterwards, lane-parallel: node = start - prefix sum
+                    // of the distances, column = start - k, peek = "the next record is a match" (a step's peek is the source byte the
+                    // next step reads anyway); the steps are stored 64 at a time.
+                    int rec = 0;
+                    const int k0 = pend ? 1 : 0;                 // lane 0: the diagonal step that was waiting for its peek (distance 0)
+                    int k = k0, ones = 0, sb;
+                    const int base_idx = pend ? pend_idx : ns, start1 = num1, start2 = num2;
+                    if (pend) wlane(rec, pend_code & 0xff, 0);
                     int a = wi * 64 + wc;                        // byte of the cell in the window's source array
                     int why;                                     // 0: the cell is not a linked diagonal move, 1: left the window / buffer full, 2: the walk is over
                     for (;;) {
-                        const int sb = __builtin_amdgcn_readfirstlane((int)wb[a]);
-                        const int fb = __builtin_amdgcn_readfirstlane((int)wb[2 * kWalkRows * 64 + a]);
-                        if (k > 0) wlane(bufW, prev_code | (((unsigned)(sb - 42) < 42u) ? 256 : 0), k - 1);
-                        const int d = (fb >> 3) & 31;
+                        sb = __builtin_amdgcn_readfirstlane((int)wb[a]);
+                        const int d = (__builtin_amdgcn_readfirstlane((int)wb[2 * kWalkRows * 64 + a]) >> 3) & 31;
                         if ((unsigned)(sb - 42) >= 84u || d == 0) { why = 0; break; }
-                        wlane(bufN, num1, k); wlane(bufC, num2, k); prev_code = sb; ++k; ++ns;
+                        wlane(rec, sb | (d << 8), k); ++k;
                         num1 -= d; num2 -= 1; a -= d * 64 + 1;
                         ones = (d == 1) ? ones + 1 : 0;
-                        if (num2 < 0) { wlane(bufW, prev_code, k - 1); why = 2; break; }            // (no next cell: peek 0)
-                        if (ones >= 8) try_probe = true;                                            // a backbone stretch: probe it
+                        if (num2 < 0) { why = 2; break; }
                         if (num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8) { why = 1; break; }
                     }
-                    // entries 0 .. k-1 are complete, except the last one when the loop stopped for the window / the buffer
+                    ns += k - k0;
+                    if (why == 1 && ones >= 8) try_probe = true;                                    // a backbone stretch: probe it
+                    if (why == 0) wlane(rec, sb & 0xff, k);      // (k <= 63 here) the cell the chain stopped at: the last step's peek
+                    const int code_l = rec & 0xff, d_l = rec >> 8;
+                    int pre = d_l;                               // inclusive prefix sum of the distances over the lanes (DPP, VALU only)
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false);
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x142, 0xa, 0xf, false);
+                    pre += __builtin_amdgcn_update_dpp(0, pre, 0x143, 0xc, 0xf, false);
+                    int node_l = start1 - (pre - d_l), col_l = start2 - (lane - k0);
+                    if (pend && lane == 0) { node_l = pend_node; col_l = pend_col; }
+                    const int nxt_code = __builtin_amdgcn_update_dpp(0, code_l, 0x130, 0xf, 0xf, false);      // lane l+1's (wave_shl:1)
+                    int peek_l = ((unsigned)(nxt_code - 42) < 42u) ? 1 : 0;
+                    if (why == 2 && lane == k - 1) peek_l = 0;                                      // (no next cell)
+                    // entries 0 .. k-1 are complete, except the last one when the chain stopped for the window / the buffer
                     int done = k;
+                    pend = false;
                     if (why == 1) {
                         done = k - 1;
-                        pend = true; pend_node = __builtin_amdgcn_readlane(bufN, k - 1); pend_col = __builtin_amdgcn_readlane(bufC, k - 1);
-                        pend_code = prev_code; pend_idx = base_idx + k - 1;
+                        pend = true; pend_node = __builtin_amdgcn_readlane(node_l, k - 1); pend_col = __builtin_amdgcn_readlane(col_l, k - 1);
+                        pend_code = __builtin_amdgcn_readlane(code_l, k - 1); pend_idx = base_idx + k - 1;
                     }
                     if (lane < done) {
-                        tsta_poa_step st; st.node = bufN; st.col = bufC; st.code = (int8_t)(bufW & 0xff); st.peek = (int8_t)(bufW >> 8); st.pad = 0;
+                        tsta_poa_step st; st.node = node_l; st.col = col_l; st.code = (int8_t)code_l; st.peek = (int8_t)peek_l; st.pad = 0;
                         A.steps[base_idx + lane] = st;
                     }
                     if (why != 0) continue;
-                    wi = num1 - rw0; wc = num2 - cw0;            // (the cell the loop stopped at: still inside the window)
+                    wi = num1 - rw0; wc = num2 - cw0;            // (the cell the chain stopped at: still inside the window)
                 }
                 const int sb = __builtin_amdgcn_readfirstlane((int)wb[wi * 64 + wc]);
                 const int fb = __builtin_amdgcn_readfirstlane((int)wb[(2 * kWalkRows + wi) * 64 + wc]);
