@@ -549,15 +549,17 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         __syncthreads();
         // one trace byte of array a at a wave-uniform (row, col): from the window (the same LDS address in every lane) or,
         // outside it, from memory; two separate loads (a select between the two addresses would make it a flat load)
+        // (the value is made scalar INSIDE each branch: the wait for it then sits in that branch — a wait at the join would be for
+        // both counters, and vmcnt also counts the step stores still in flight: ~1 us per gap step)
         auto rdu = [&](int a, int row, int col) -> int {
             const int x = row - rw0, y = col - cw0;
             int v;
-            if ((unsigned)x < (unsigned)kWalkRows && (unsigned)y < 64u) v = wb[(a * kWalkRows + x) * 64 + y];
+            if ((unsigned)x < (unsigned)kWalkRows && (unsigned)y < 64u) v = __builtin_amdgcn_readfirstlane((int)wb[(a * kWalkRows + x) * 64 + y]);
             else {
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
-                v = *(GlobalI8*)(base + (size_t)row * A.tpitch + col);
+                v = __builtin_amdgcn_readfirstlane((int)*(GlobalI8*)(base + (size_t)row * A.tpitch + col));
             }
-            return __builtin_amdgcn_readfirstlane(v);
+            return v;
         };
         for (;;) {
             if (num1 < 0 || num2 < 0) break;
