@@ -297,6 +297,20 @@ def test_reference_arithmetic_fuzz(eng):
                 continue
             want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W, **sc)
             assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:])), (it, V, n, mp, W, sc)
+        # the largest lane state the kernel takes: in-degree 32 at -W 32 = 152 KB of dynamic LDS (+ 7 KB static of the CU's 160 KB)
+        pred_off, pred, base, is_sink, seq = random_dag(77, 300, 32, 700)
+        assert int(np.max(np.diff(pred_off))) == 32
+        seq = sprinkle_n(seq, 77, (), 3)
+        eng.set_option("poa_ref_block", 64 * 32)
+        got = eng.poa_fill(pred_off, pred, base, is_sink, seq)
+        assert eng.last_status == 0
+        want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, 32)
+        assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:]))
+        # ... and one predecessor more does not fit: the plain DP with its warning
+        pred_off, pred, base, is_sink, seq = random_dag(78, 300, 33, 700)
+        if int(np.max(np.diff(pred_off))) == 33:
+            eng.poa_fill(pred_off, pred, base, is_sink, sprinkle_n(seq, 78, (), 3))
+            assert eng.last_status == 1 and "literal 'N'" in eng.last_warning()
     finally:
         eng.set_option("poa_ref_block", 640)
 
