@@ -86,7 +86,7 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      bytes: only what the next step needs is on the chain of dependent steps) and computes the trace bytes in
  *                      independent EMITTER tiles that restart from checkpoints the solvers leave (psa_trace_split_kernel) | 0: never |
  *                      2: at any size (tests)
- *   "poa_dataflow"     1 (default): POA fill as one launch, one workgroup per 128-column chunk with a solver wave, four emitter
+ *   "poa_dataflow"     1 (default): POA fill as one launch, one workgroup per 128-column chunk with a solver wave, five emitter
  *                      waves and a fetcher wave (poa_dataflow.hip; sequences without 'N').  Roles are tickets drawn in start
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
  *                      waits all the same, the call is run again through the other form | 0: always one launch per tile

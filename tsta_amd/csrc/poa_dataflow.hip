@@ -39,8 +39,8 @@ namespace tsta {
 constexpr int kDfKC = 2;                 // columns per lane
 constexpr int kDfCW = 64 * kDfKC;        // columns per chunk
 constexpr int kDfRB = 32;                // nodes per block
-constexpr int kDfThreads = 384;          // solver (wave 0), emitters (waves 1-3 and 5), fetcher (wave 4)
-constexpr int kDfEmit = 4;               // emitter waves
+constexpr int kDfThreads = 448;          // solver (wave 0), emitters (waves 1-3, 5, 6), fetcher (wave 4)
+constexpr int kDfEmit = 5;               // emitter waves
 constexpr int kDfRing = 3 * kDfRB;       // rows whose records stay in LDS: three blocks (the solver writes one and reads the one before it,
                                          // the emitters of that one still read the third): 96 x 6 x 64 ints = 144 KB
 
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0) here: or every row would wait for the stores of the row before
             int spread_l = 0;
             // the block's side data (the solver wrote them before the block's first record), one row per lane
-            const int em = (wave == 5) ? 3 : wave - 1;        // emitter number: rows em, em + 4, ...
+            const int em = (wave >= 5) ? wave - 2 : wave - 1; // emitter number: rows em, em + kDfEmit, ...
             int seen = 0;
             const bool live = (em >= nrows) || lds_wait_gt_seen(&produced[lane], rows_base + em, seen, P.status, lane);
             if (!live) return;                                // (abandoned launch)
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(kDfThreads) void poa_dataflow_kernel(PoaDfArgs P)
             }
         }
         // No barrier: the solver runs on into the next block while the emitters finish this one.  Every wave, once ITS stores
-        // of the block have left, counts itself in; the fourth one publishes the block — to the chunk on the right (prog[q+1],
+        // of the block have left, counts itself in; the last one publishes the block — to the chunk on the right (prog[q+1],
         // sc1) and to this workgroup's solver (blk_pub: it may then recycle the block's ring third two blocks later).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
