@@ -297,6 +297,9 @@ def test_reference_arithmetic_fuzz(eng):
                 continue
             want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, W, **sc)
             assert got[0] == want[0] and all(np.array_equal(g, w) for g, w in zip(got[1:], want[1:])), (it, V, n, mp, W, sc)
+            if it % 5 == 0:                                      # scores only (no trace arrays on the device)
+                best, last = eng.poa_fill(pred_off, pred, base, is_sink, seq, tsta_amd.Params(**sc), want_trace=False)[:2]
+                assert best == want[0] and np.array_equal(last, want[1]), (it, "no trace")
         # the largest lane state the kernel takes: in-degree 32 at -W 32 = 152 KB of dynamic LDS (+ 7 KB static of the CU's 160 KB)
         pred_off, pred, base, is_sink, seq = random_dag(77, 300, 32, 700)
         assert int(np.max(np.diff(pred_off))) == 32
