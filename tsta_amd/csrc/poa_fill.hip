@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         auto rdu = [&](int a, int row, int col) -> int {
             const int x = row - rw0, y = col - cw0;
             int v;
-            if ((unsigned)x < (unsigned)kWalkRows && (unsigned)y < 64u) v = __builtin_amdgcn_readfirstlane((int)wb[(a * kWalkRows + x) * 64 + y]);
+            if (__builtin_expect((unsigned)x < (unsigned)kWalkRows && (unsigned)y < 64u, 1)) v = __builtin_amdgcn_readfirstlane((int)wb[(a * kWalkRows + x) * 64 + y]);
             else {
                 const int8_t* base = (a == 0 ? A.source : (a == 1 ? A.esource : A.fsource));
                 v = __builtin_amdgcn_readfirstlane((int)*(GlobalI8*)(base + (size_t)row * A.tpitch + col));
@@ -562,11 +562,11 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             return v;
         };
         for (;;) {
-            if (num1 < 0 || num2 < 0) break;
+            if (__builtin_expect(num1 < 0 || num2 < 0, 0)) break;
             int wi = num1 - rw0, wc = num2 - cw0;
-            if ((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u) break;                 // restage
+            if (__builtin_expect((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u, 0)) break;                 // restage
             if constexpr (LINKS) {
-                if (forced < 0 && try_probe) {
+                if (__builtin_expect(forced < 0 && try_probe, 0)) {          // (laid out of line: where it runs, a probe takes up to 64 cells)
                     // ---- a run of backbone cells (diagonal moves to the row just above: link distance 1) is taken at once: lane l
                     // probes cell (num1 - l, num2 - l), as the walker of the K4 path does with its predecessor bits.  Worth it only
                     // in such stretches: a short run switches the probe off, the loop below switches it on again.
@@ -616,12 +616,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                     for (;;) {
                         sb = __builtin_amdgcn_readfirstlane((int)wb[a]);
                         const int d = (__builtin_amdgcn_readfirstlane((int)wb[2 * kWalkRows * 64 + a]) >> 3) & 31;
-                        if ((unsigned)(sb - 42) >= 84u || d == 0) { why = 0; break; }
+                        if (__builtin_expect((unsigned)(sb - 42) >= 84u || d == 0, 0)) { why = 0; break; }
                         wlane(rec, sb | (d << 8), k); ++k;
                         num1 -= d; num2 -= 1; a -= d * 64 + 1;
                         ones = (d == 1) ? ones + 1 : 0;
-                        if (num2 < 0) { why = 2; break; }
-                        if (num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8) { why = 1; break; }
+                        if (__builtin_expect(num2 < 0, 0)) { why = 2; break; }
+                        if (__builtin_expect(num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8, 0)) { why = 1; break; }
                     }
                     ns += k - k0;
                     if (why == 1 && ones >= 8) try_probe = true;                                    // a backbone stretch: probe it
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 }
                 const int sb = __builtin_amdgcn_readfirstlane((int)wb[wi * 64 + wc]);
                 const int fb = __builtin_amdgcn_readfirstlane((int)wb[(2 * kWalkRows + wi) * 64 + wc]);
-                if (pend) {                                    // the step before was a diagonal move to this cell
+                if (__builtin_expect(pend, 0)) {               // the step before was a diagonal move to this cell
                     if (lane == 0) {
                         tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code;
                         st.peek = (int8_t)(((unsigned)(sb - 42) < 42u) ? 1 : 0); st.pad = 0;
@@ -667,12 +667,12 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                 const bool was_forced = forced >= 0;
                 const int code = was_forced ? forced : sb;
                 forced = -1;
-                if (code < 0) { bad = true; num1 = -1; break; }
+                if (__builtin_expect(code < 0, 0)) { bad = true; num1 = -1; break; }
                 const int kind = code / 42, pidx = code % 42;
                 int Psub = -1;
                 const int d = (fb >> 3) & 31;
                 if (kind != 3) {
-                    if (!was_forced && d != 0) Psub = num1 - d;
+                    if (__builtin_expect(!was_forced && d != 0, 1)) Psub = num1 - d;
                     else {
                         const int np = __builtin_amdgcn_readfirstlane(wnp[wi]);
                         if (pidx < np) {
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                             else Psub = __builtin_amdgcn_readfirstlane(A.pred[__builtin_amdgcn_readfirstlane(wpo[wi]) + pidx]);
                         }
                     }
-                    if (Psub < -1 || Psub >= num1) { bad = true; num1 = -1; break; }
+                    if (__builtin_expect(Psub < -1 || Psub >= num1, 0)) { bad = true; num1 = -1; break; }
                 }
                 int n1 = num1, n2 = num2;
                 bool defer = false;

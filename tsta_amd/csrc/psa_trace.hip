@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
             const int ct = cj - 1 + cl, cq = ct / SPB;
             const size_t off = ((size_t)cq * 64 + cl) * 16 + (ct % SPB) * R + ck;
             // (made uniform inside each branch: the LDS path then waits for the LDS only, not for the prefetch in flight)
-            if (cw == w && cq >= qlo && cq <= qhi) return (unsigned)__builtin_amdgcn_readfirstlane((int)wb[off - (size_t)qlo * 64 * 16]);
+            if (__builtin_expect(cw == w && cq >= qlo && cq <= qhi, 1)) return (unsigned)__builtin_amdgcn_readfirstlane((int)wb[off - (size_t)qlo * 64 * 16]);
             return (unsigned)__builtin_amdgcn_readfirstlane((int)*(GlobalConstU8*)(A.trace + (size_t)cw * A.band_bytes + off));
         };
         // byte of cell (ci,cj) inside the staged window, or -1
@@ -696,20 +696,20 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
         // two cells at once (the gap rules look at the next two cells in the gap's direction): both LDS reads go out together
         auto code2 = [&](int ai, int aj, int bi, int bj, unsigned& ca, unsigned& cb) {
             const int oa = win_off(ai, aj), ob = win_off(bi, bj);
-            if (oa >= 0 && ob >= 0) {
+            if (__builtin_expect(oa >= 0 && ob >= 0, 1)) {
                 const int va = wb[oa], vb = wb[ob];
                 ca = (unsigned)__builtin_amdgcn_readfirstlane(va); cb = (unsigned)__builtin_amdgcn_readfirstlane(vb);
             } else { ca = code(ai, aj); cb = code(bi, bj); }
         };
         for (;;) {
-            if (i < 1 || j < 1) break;
+            if (__builtin_expect(i < 1 || j < 1, 0)) break;
             {
                 const int cw = (i - 1) / BAND, cl = ((i - 1) % BAND) / R;
                 const int cq = (j - 1 + cl) / SPB;
-                if (cw != w || cq < qlo) break;                  // left the window: restage
+                if (__builtin_expect(cw != w || cq < qlo, 0)) break;                  // left the window: restage
             }
             unsigned c = 0;
-            if (forced < 0) {
+            if (__builtin_expect(forced < 0, 1)) {
                 // ---- diagonal run: lane l probes cell (i-l, j-l); the run of leading "diag" cells is taken at once
                 const int ci = i - lane, cj = j - lane;
                 bool isdiag = false, seen = false;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
                 }
                 const unsigned long long mask = __ballot(isdiag);
                 const int run = (~mask == 0ull) ? 64 : __builtin_ctzll(~mask);
-                if (run > 0) {
+                if (__builtin_expect(run > 0, 1)) {
                     if (lane < run) *(GlobalU8*)(A.ops + cnt + lane) = 1;
                     i -= run; j -= run; cnt += run;
                     // the cell that ended the run was probed too (lane `run`): its step follows without another probe
