@@ -1,8 +1,8 @@
 # round 3 profiles: default bench line (with configs #2/#3/#4/5t), rocprofv3 kernel stats of the headline command, PMC traffic
-# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>  (profiles/r03j_* = this script on the final build of round 3, condensed by tools/collect_profiles.py)
+# (separate passes), SQ counters, the configs with their kernel stats.  Run on the GPU box: bash tools/scripts/r03_profiles.sh <tag>  (profiles/r03k_* = this script on the final build of round 3, condensed by tools/collect_profiles.py)
 set -e
 export TMPDIR=/tmp
-TAG=${1:-r03j}
+TAG=${1:-r03k}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python -c "import tsta_amd; print(tsta_amd.build_info(), tsta_amd.source_hash())" > $O/build_info.txt 2>&1
 timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err

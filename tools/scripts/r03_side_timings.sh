@@ -1,8 +1,8 @@
-# round 3: the timings DESIGN.md quotes outside the bench line, on the final build, into one text file (profiles/r03j_side_timings.txt):
+# round 3: the timings DESIGN.md quotes outside the bench line, on the final build, into one text file (profiles/r03k_side_timings.txt):
 # TSTA_msa start-up breakdown next to the reference, wide MSAs (4 x 30 kbp, 3 x 100 kbp: K4d against K4), the K4e path (per fill and
 # end to end on the README example with three N's).  Run on the GPU box: bash tools/scripts/r03_side_timings.sh <tag>
 export TMPDIR=/tmp
-TAG=${1:-r03j}
+TAG=${1:-r03k}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 F=$O/side_timings.txt
 python -c "import tsta_amd; print(tsta_amd.build_info())" > $F 2>&1
