@@ -9,8 +9,9 @@
  * exit()s / crashes on errors, seqio.c:38,47,180; c-t-simd.c:154).
  *
  * STATUS CONVENTION: rc < 0 is a failure (outputs invalid), rc == 0 success, rc > 0 success WITH A WARNING (outputs valid;
- * today only TSTA_WARN_REFERENCE_UNDEFINED from tsta_poa_fill / tsta_poa_align, e.g. for any sequence containing 'N').
- * Test with TSTA_FAILED(rc), never with rc != TSTA_OK.
+ * today only TSTA_WARN_REFERENCE_UNDEFINED: from every tsta_psa_* entry point when the SCORING lies outside the domain in which
+ * the reference's int8 encoding is exact (tsta_psa_reference_exact), and from tsta_poa_fill / tsta_poa_align where the
+ * reference-arithmetic path cannot run).  Test with TSTA_FAILED(rc), never with rc != TSTA_OK.
  *
  * Threading: one engine per host thread / per GPU.  An engine owns its device workspaces.
  */
@@ -24,8 +25,8 @@ extern "C" {
 
 typedef enum tsta_status {
     /* > 0: the call SUCCEEDED and its outputs are valid, but the REFERENCE's own output on this input is not a function
-     * of the input and the scoring alone: it depends on -W / the SIMD width of the build (tsta_poa_fill / tsta_poa_align
-     * document the three cases).  tsta_last_warning() says which one was seen. */
+     * of the input and the scoring alone: it depends on -W / the SIMD width of the build (tsta_psa_reference_exact documents
+     * the PSA case, tsta_poa_fill / tsta_poa_align the POA cases).  tsta_last_warning() says which one was seen. */
     TSTA_WARN_REFERENCE_UNDEFINED = 1,
     TSTA_OK = 0,
     TSTA_ERR_INVALID_ARG = -1,
@@ -113,8 +114,28 @@ int  tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value);
  *
  * seqs: concatenated sequence bytes (any byte values; compared for equality, case-sensitive, psa.c:253).
  * off1/len1, off2/len2: start offset and length of the -1 / -2 sequence of each pair.
- * Exactness domain: |H| must fit int32 (always true for lengths < 2^24 and |params| <= 127).
+ * Exactness domain of the engine: |H| must fit int32 (always true for lengths < 2^24 and |params| <= 127).
+ *
+ * WHAT IS COMPUTED, AND WHERE IT IS WHAT THE REFERENCE PRINTS.  Every tsta_psa_* entry point computes the plain integer
+ * affine-gap DP.  The reference computes the same DP in int8 DIFFERENCES with wrap-around adds and
+ * MIN = -100 as minus infinity (psa.c:110,219-232,244-246,285-327); inside the scoring domain below its output is that DP for
+ * every input, independent of ISA, -T and -W (88 + 200 golden cases from the compiled reference, three ISAs, two -W).  Outside
+ * it the reference's int8 arithmetic wraps: its printed maxsorce and its alignment then depend on the SIMD width of the build and
+ * on -W (e.g. -E -30: 126379 at -W 10, 155324 at -W 3, where the DP gives 518) — "reference-undefined".  There the engine still
+ * returns the plain DP, and says so: the call returns TSTA_WARN_REFERENCE_UNDEFINED (> 0, outputs valid) and
+ * tsta_last_warning() names the first condition that failed.  With g = O + E, S = max(M, 0), s = min(M, X) the domain is
+ *     E <= 0, O <= 0, X <= 0,   E >= -28,   2g + E >= -128,   S - g <= 127,   s >= -128,   max(s, 2g) + g >= -128,
+ *     2g >= -100  or  s + O >= -100
+ * (each is one statement of row() staying inside int8, or MIN really acting as minus infinity; engine.hip: psa_reference_exact;
+ * X <= 0 because the reference's maximum also runs over its padded columns, psa.c:333-357).  Conservative by construction; scanned
+ * against the compiled reference on tests/golden/psa_domain_golden.json: no in-domain case differs from the DP, every scanned
+ * out-of-domain case does.  One more reference-undefined input is NOT detectable: the reference leaves the padding of its column
+ * sequence uninitialised (psa.c:206-210), so a padded column whose garbage byte equals a base can raise its maxsorce.
  * ------------------------------------------------------------------------------------------------ */
+
+/* 1: the scoring is inside the domain above (the reference prints what the engine computes), 0: outside; < 0: tsta_status.
+ * why (may be NULL) receives the text tsta_last_warning() would carry ("" inside the domain).  Pure host arithmetic. */
+int tsta_psa_reference_exact(const tsta_params* p, char* why, size_t why_bytes);
 
 /* Host-pointer form (copies in, runs, copies out, synchronises). */
 int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "tsta_multi_create", "tsta_multi_destroy", "tsta_multi_device_count", "tsta_multi_engine", "tsta_multi_last_error",
     "tsta_multi_set_option", "tsta_shard_bounds", "tsta_psa_score_batch_multi", "tsta_psa_align_batch_multi",
     "tsta_build_info", "tsta_device_uuid", "tsta_last_warning", "tsta_psa_score_batch_dev_status", "tsta_engine_stat",
+    "tsta_psa_reference_exact",
 ]
 
 
@@ -108,6 +109,7 @@ def lib():
         L.tsta_build_info.restype = C.c_char_p; L.tsta_build_info.argtypes = []
         L.tsta_device_uuid.restype = C.c_int; L.tsta_device_uuid.argtypes = [C.c_int, C.c_char_p]
         L.tsta_shard_bounds.restype = C.c_int; L.tsta_shard_bounds.argtypes = [i64, vp, vp, C.c_int, vp]
+        L.tsta_psa_reference_exact.restype = C.c_int; L.tsta_psa_reference_exact.argtypes = [C.POINTER(Params), C.c_char_p, C.c_size_t]
         L.tsta_multi_create.restype = C.c_int; L.tsta_multi_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.tsta_multi_destroy.restype = None; L.tsta_multi_destroy.argtypes = [vp]
         L.tsta_multi_device_count.restype = C.c_int; L.tsta_multi_device_count.argtypes = [vp]
@@ -182,6 +184,16 @@ def shard_bounds(len1, len2, n_shards):
     return b
 
 
+def psa_reference_exact(params=None, **kw):
+    """tsta_psa_reference_exact: (inside, why) — is the reference's PSA output the plain DP for this scoring?  No device needed."""
+    params = params or Params(**kw)
+    buf = C.create_string_buffer(512)
+    rc = lib().tsta_psa_reference_exact(C.byref(params), buf, len(buf))
+    if rc < 0:
+        raise TstaError("tsta_psa_reference_exact: %s" % lib().tsta_strerror(rc).decode())
+    return bool(rc), buf.value.decode()
+
+
 class Multi:
     """Several GPUs of one node (mirrors ``tsta_multi``): a batch is sharded over the devices, one engine each."""
 
@@ -208,8 +220,13 @@ class Multi:
             pass
 
     def _check(self, rc, what):
-        if rc != 0:
+        # rc > 0 = TSTA_WARN_* (success; text: tsta_last_warning of engine 0); rc < 0 = error
+        self.last_status = int(rc)
+        if rc < 0:
             raise TstaError("%s: %s (%s)" % (what, lib().tsta_strerror(rc).decode(), lib().tsta_multi_last_error(self._h).decode()))
+
+    def last_warning(self):
+        return lib().tsta_last_warning(lib().tsta_multi_engine(self._h, 0)).decode()
 
     def set_option(self, key, value):
         self._check(lib().tsta_multi_set_option(self._h, key.encode(), int(value)), "tsta_multi_set_option(%s)" % key)

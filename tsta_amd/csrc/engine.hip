@@ -50,6 +50,51 @@ int Engine::reserve(DevBuf& b, size_t bytes, const char* what, bool growing)
     return TSTA_OK;
 }
 
+// Where the reference's PSA output IS the plain DP the kernels compute (tsta_engine.h: tsta_psa_reference_exact).  The reference
+// keeps every quantity of row() as an int8 DIFFERENCE against H(i-1,j-1) and adds / subtracts with wrap-around
+// (mm_add_epi8 / mm_sub_epi8, psa.c:244-246,285-327); its "minus infinity" is MIN = -100 (psa.c:110).  With g = O + E,
+// S = max(M, 0), s_min = min(M, X), the true ranges of those quantities are
+//   e, f (gap states)            in [2g, S]          psa.c:225-231 (init 2E+O, 2(E+O)), :324, :310
+//   h1 = s + ogap                in [max(s_min, 2g) + g, S + g]                                    :301
+//   t, v (horizontal / vertical) in [g, S - g]                                                       :291, :329
+// and each condition below says that one statement of row() stays inside int8 (or that MIN really acts as minus infinity);
+// the first one that fails is reported.  Conservative by construction, and checked against the compiled reference (3 ISAs, two
+// -W) on the grid of tests/golden/psa_domain_golden.json: no in-domain case differs, and every scanned out-of-domain case does.
+bool psa_reference_exact(const tsta_params* p, char* why, size_t cap)
+{
+    const int M = p->M, X = p->X, E = p->E, O = p->O;
+    const long long g = (long long)O + E, S = std::max(M, 0), smin = std::min(M, X);
+    const char* w = nullptr;
+    char buf[200];
+    if (E > 0 || O > 0)
+        w = "a positive gap score: the reference's lazy-F pass (psa.c:266-274) assumes E, O <= 0";
+    else if (X > 0)
+        w = "a positive mismatch score: the reference's maximum runs over its padded columns too (psa.c:333-357), which then outscore the real cells";
+    else if (E < -28)
+        w = "E < -28: MIN + E = -100 + E wraps around in int8 in the first pass (psa.c:110,260)";
+    else if (2 * g + E < -128)
+        w = "2(O+E)+E < -128: a gap state at its minimum 2(O+E) wraps when extended (psa.c:260,303,319)";
+    else if (S - g > 127)
+        w = "max(M,0)-O-E > 127: the horizontal / vertical difference M-(O+E) does not fit int8 (psa.c:291,329)";
+    else if (smin < -128)
+        w = "min(M,X) < -128: the substitution score itself does not fit int8 (psa.c:242-243)";
+    else if (std::max(smin, 2 * g) + g < -128)
+        w = "max(min(M,X),2(O+E))+O+E < -128: H+O+E against the diagonal wraps (psa.c:259,301)";
+    else if (2 * g < -100 && smin + O < -100)
+        w = "2(O+E) < -100 and min(M,X)+O < -100: real gap states lie below the reference's MIN = -100 (psa.c:110,247)";
+    if (w && why && cap) {
+        snprintf(buf, sizeof(buf), "M=%d X=%d E=%d O=%d: %s", M, X, E, O, w);
+        snprintf(why, cap, "scoring outside the domain where the reference's int8 difference encoding is exact (%s): the reference's own "
+                 "output there depends on its SIMD width and -W; this result is the plain affine-gap DP", buf);
+    } else if (why && cap) why[0] = 0;
+    return w == nullptr;
+}
+
+int psa_reference_warning(Engine* e, const tsta_params* p)
+{
+    return psa_reference_exact(p, e->warn, sizeof(e->warn)) ? TSTA_OK : TSTA_WARN_REFERENCE_UNDEFINED;
+}
+
 void Engine::timing_begin(hipStream_t s) { timing_stream = s; n_launches = 0; (void)hipEventRecord(ev0, s); }
 void Engine::timing_end(hipStream_t s) { (void)hipEventRecord(ev1, s); timing_valid = true; }
 
@@ -95,6 +140,12 @@ int tsta_device_uuid(int device, char* out33)
     if (hipDeviceGetUuid(&u, device) != hipSuccess) { (void)hipGetLastError(); return TSTA_ERR_HIP; }
     for (int i = 0; i < 16; ++i) snprintf(out33 + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
     return TSTA_OK;
+}
+
+int tsta_psa_reference_exact(const tsta_params* p, char* why, size_t why_bytes)
+{
+    if (!p) return TSTA_ERR_INVALID_ARG;
+    return tsta::psa_reference_exact(p, why, why_bytes) ? 1 : 0;
 }
 
 const char* tsta_last_warning(const tsta_engine* eng)

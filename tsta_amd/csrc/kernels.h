@@ -103,5 +103,12 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
                          const int64_t* off1, const int32_t* len1, const int64_t* off2, const int32_t* len2,
                          int32_t* out, int64_t dev_count, int32_t** d_scores);
 int  psa_packed_blocks_per_cu(int R);
+// engine.hip: is the reference's PSA output the plain DP for this scoring (tsta_engine.h: tsta_psa_reference_exact)?  The second
+// form is what every PSA entry point ends a successful call with: sets e->warn, returns TSTA_OK or TSTA_WARN_REFERENCE_UNDEFINED.
+bool psa_reference_exact(const tsta_params* p, char* why, size_t cap);
+int  psa_reference_warning(Engine* e, const tsta_params* p);
+// psa_api.hip: the bodies of tsta_psa_score_batch_dev[_2bit] (TSTA_OK or an error; the public forms add the warning)
+int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs, const int64_t* d_off1,
+                             const int32_t* d_len1, const int64_t* d_off2, const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream);
 
 }  // namespace tsta

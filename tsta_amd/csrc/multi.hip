@@ -133,7 +133,7 @@ static int make_shards(Multi* m, int64_t n_pairs, int64_t seqs_bytes, const int6
 static int first_failure(Multi* m, const std::vector<Shard>& sh, const char* what)
 {
     for (int d = 0; d < m->n(); ++d)
-        if (sh[d].rc != TSTA_OK) {
+        if (TSTA_FAILED(sh[d].rc)) {          // a TSTA_WARN_* of a shard is a success (the callers add the scoring warning themselves)
             m->set_error("%s on device %d: %s (%s)", what, m->devices[d], tsta_strerror(sh[d].rc), tsta_last_error(m->eng[d]));
             return sh[d].rc;
         }
@@ -253,7 +253,9 @@ int tsta_psa_score_batch_multi(tsta_multi* mm, const tsta_params* p, int64_t n_p
     work(0);
     for (std::thread& t : th) t.join();
     if ((rc = tsta::first_failure(m, sh, "tsta_psa_score_batch")) != TSTA_OK) return rc;
-    if (!use_rccl) return TSTA_OK;
+    // the scoring-domain warning (tsta_psa_reference_exact) is a property of `p` alone: its text goes to engine 0
+    const int warn = tsta::psa_reference_warning(reinterpret_cast<tsta::Engine*>(m->eng[0]), p);
+    if (!use_rccl) return warn;
 
     // ---- the path's only collective: all-gather of the padded int32 shards (RCCL over xGMI), one grouped call
     for (int d = 0; d < nd; ++d) {
@@ -297,7 +299,7 @@ int tsta_psa_score_batch_multi(tsta_multi* mm, const tsta_params* p, int64_t n_p
     }
     for (int q = 0; q < nd; ++q)
         memcpy(out + sh[q].lo, &host[(size_t)q * max_shard], (size_t)(sh[q].hi - sh[q].lo) * sizeof(int32_t));
-    return TSTA_OK;
+    return warn;
 }
 
 int tsta_psa_align_batch_multi(tsta_multi* mm, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
@@ -323,8 +325,8 @@ int tsta_psa_align_batch_multi(tsta_multi* mm, const tsta_params* p, int64_t n_p
     for (int d = 1; d < nd; ++d) th.emplace_back(work, d);
     work(0);
     for (std::thread& t : th) t.join();
-    if ((rc = tsta::first_failure(m, sh, "tsta_psa_align_batch")) != TSTA_OK) tsta_alignments_free(out, n_pairs);
-    return rc;
+    if ((rc = tsta::first_failure(m, sh, "tsta_psa_align_batch")) != TSTA_OK) { tsta_alignments_free(out, n_pairs); return rc; }
+    return tsta::psa_reference_warning(reinterpret_cast<tsta::Engine*>(m->eng[0]), p);
 }
 
 }  // extern "C"

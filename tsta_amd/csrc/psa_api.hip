@@ -168,17 +168,16 @@ static const uint32_t* psa_order_by_geometry(Engine* e, const int32_t* d_len1, c
 
 }  // namespace tsta
 
-extern "C" {
+namespace tsta {
 
-int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs,
+int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs,
                              const int64_t* d_off1, const int32_t* d_len1, const int64_t* d_off2,
                              const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
 {
-    if (!eng || !p || n_pairs < 0 || max_len < 0) return TSTA_ERR_INVALID_ARG;
+    if (!e || !p || n_pairs < 0 || max_len < 0) return TSTA_ERR_INVALID_ARG;
     if (n_pairs == 0) return TSTA_OK;
     if (!d_seqs || !d_off1 || !d_len1 || !d_off2 || !d_len2 || !d_out) return TSTA_ERR_INVALID_ARG;
     if (n_pairs > 0x7fffffffLL) return TSTA_ERR_UNSUPPORTED;
-    Engine* e = reinterpret_cast<Engine*>(eng);
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
@@ -339,12 +338,29 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
     return e->check(hipGetLastError(), "psa_score_batch launch");
 }
 
+}  // namespace tsta
+
+extern "C" {
+
+// Every PSA entry point ends a successful call with psa_reference_warning(): TSTA_OK, or TSTA_WARN_REFERENCE_UNDEFINED when the
+// scoring lies outside the domain in which the reference's int8 encoding computes this DP (tsta_psa_reference_exact).
+int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_seqs,
+                             const int64_t* d_off1, const int32_t* d_len1, const int64_t* d_off2,
+                             const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
+{
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = tsta::psa_score_batch_dev_impl(e, p, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream);
+    return rc == TSTA_OK ? tsta::psa_reference_warning(e, p) : rc;
+}
+
 int tsta_psa_score_batch(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* seqs,
                          int64_t seqs_bytes, const int64_t* off1, const int32_t* len1,
                          const int64_t* off2, const int32_t* len2, int32_t* out)
 {
     if (!out && n_pairs > 0) return TSTA_ERR_INVALID_ARG;
-    return tsta::psa_score_batch_host(reinterpret_cast<Engine*>(eng), p, n_pairs, seqs, seqs_bytes, off1, len1, off2, len2, out, 0, nullptr);
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = tsta::psa_score_batch_host(e, p, n_pairs, seqs, seqs_bytes, off1, len1, off2, len2, out, 0, nullptr);
+    return rc == TSTA_OK ? tsta::psa_reference_warning(e, p) : rc;
 }
 
 }  // extern "C"
@@ -433,11 +449,11 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
         (rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
         (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")))
         return rc;
-    rc = tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+    rc = psa_score_batch_dev_impl(e, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                   d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
     if ((rc = psa_score_rerun_if_abandoned(e, [&] {
-            return tsta_psa_score_batch_dev(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+            return psa_score_batch_dev_impl(e, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                             d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s); })) != TSTA_OK)
         return rc;
     if (out && (rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
@@ -464,14 +480,13 @@ int tsta_pack_2bit(const uint8_t* src, int64_t n, uint8_t* dst)
     return TSTA_OK;
 }
 
-int tsta_psa_score_batch_dev_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_packed,
-                                  const int64_t* d_boff1, const int32_t* d_len1, const int64_t* d_boff2,
-                                  const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
+static int psa_score_batch_dev_2bit_impl(Engine* e, const tsta_params* p, int64_t n_pairs, const uint8_t* d_packed,
+                                        const int64_t* d_boff1, const int32_t* d_len1, const int64_t* d_boff2,
+                                        const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
 {
-    if (!eng || !p || n_pairs < 0 || max_len < 0) return TSTA_ERR_INVALID_ARG;
+    if (!e || !p || n_pairs < 0 || max_len < 0) return TSTA_ERR_INVALID_ARG;
     if (n_pairs == 0) return TSTA_OK;
     if (!d_packed || !d_boff1 || !d_len1 || !d_boff2 || !d_len2 || !d_out) return TSTA_ERR_INVALID_ARG;
-    Engine* e = reinterpret_cast<Engine*>(eng);
     int rc = e->check(hipSetDevice(e->device), "hipSetDevice");
     if (rc != TSTA_OK) return rc;
     hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
@@ -484,7 +499,16 @@ int tsta_psa_score_batch_dev_2bit(tsta_engine* eng, const tsta_params* p, int64_
     hipLaunchKernelGGL(tsta::psa_unpack_2bit_kernel, dim3((unsigned)std::min<int64_t>(2 * n_pairs, 65536)), dim3(256), 0, s,
                        d_packed, d_boff1, d_len1, d_boff2, d_len2, n_pairs, stride, d_seqs, d_off1, d_off2);
     if ((rc = e->check(hipGetLastError(), "unpack launch")) != TSTA_OK) return rc;
-    return tsta_psa_score_batch_dev(eng, p, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream);
+    return tsta::psa_score_batch_dev_impl(e, p, n_pairs, d_seqs, d_off1, d_len1, d_off2, d_len2, d_out, max_len, stream);
+}
+
+int tsta_psa_score_batch_dev_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* d_packed,
+                                  const int64_t* d_boff1, const int32_t* d_len1, const int64_t* d_boff2,
+                                  const int32_t* d_len2, int32_t* d_out, int32_t max_len, void* stream)
+{
+    Engine* e = reinterpret_cast<Engine*>(eng);
+    int rc = psa_score_batch_dev_2bit_impl(e, p, n_pairs, d_packed, d_boff1, d_len1, d_boff2, d_len2, d_out, max_len, stream);
+    return rc == TSTA_OK ? tsta::psa_reference_warning(e, p) : rc;
 }
 
 int tsta_psa_score_batch_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_pairs, const uint8_t* packed,
@@ -524,15 +548,16 @@ int tsta_psa_score_batch_2bit(tsta_engine* eng, const tsta_params* p, int64_t n_
         (rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
         (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")))
         return rc;
-    rc = tsta_psa_score_batch_dev_2bit(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+    rc = psa_score_batch_dev_2bit_impl(e, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                        d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s);
     if (rc != TSTA_OK) return rc;
     if ((rc = tsta::psa_score_rerun_if_abandoned(e, [&] {
-            return tsta_psa_score_batch_dev_2bit(eng, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
+            return psa_score_batch_dev_2bit_impl(e, p, n_pairs, reinterpret_cast<const uint8_t*>(e->in_seqs.p), d_off1, d_len1,
                                                  d_off2, d_len2, reinterpret_cast<int32_t*>(e->out_scores.p), max_len, s); })) != TSTA_OK)
         return rc;
     if ((rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
-    return e->check(hipStreamSynchronize(s), "psa_score_batch_2bit sync");
+    if ((rc = e->check(hipStreamSynchronize(s), "psa_score_batch_2bit sync"))) return rc;
+    return tsta::psa_reference_warning(e, p);
 }
 
 }  // extern "C"

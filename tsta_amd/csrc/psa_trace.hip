@@ -1047,8 +1047,10 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             // emitters: every compute unit ends up with two workgroups (a solver workgroup and an emitter workgroup, or two of the latter)
             // one workgroup per compute unit (LDS): the solvers' CUs carry four emitter waves each, the others eight
             int n_wg = std::max(e->n_cu, A.n_solver_wg);
-            if (const char* v = getenv("TSTA_SPLIT_WG")) n_wg = std::max(A.n_solver_wg, atoi(v));     // experiments
-            if (getenv("TSTA_SPLIT_NOEMIT")) A.n_tiles = 0;                                            // experiments: solvers only (no trace!)
+#ifdef TSTA_EXPERIMENTS     // never in the shipped library: NOEMIT leaves the trace unwritten
+            if (const char* v = getenv("TSTA_SPLIT_WG")) n_wg = std::max(A.n_solver_wg, atoi(v));
+            if (getenv("TSTA_SPLIT_NOEMIT")) A.n_tiles = 0;
+#endif
             if constexpr (R == 2) {
                 // pure-ACGT pair and byte-sized substitution scores: the match / mismatch term as a table look-up (trace_step<.., ACGT>)
                 const bool acgt = e->opt_psa_perm != 0 && p->M >= -128 && p->M <= 127 && p->X >= -128 && p->X <= 127 && pure_acgt(jobs[0]);
@@ -1244,7 +1246,7 @@ extern "C" int tsta_psa_align(tsta_engine* eng, const tsta_params* p, const uint
     }
     if ((rc = assemble_rows(e, J, row_a, row_b, out_len)) != TSTA_OK) return rc;
     *maxscore = J.maxscore;
-    return TSTA_OK;
+    return psa_reference_warning(e, p);       // TSTA_OK, or the scoring is outside the reference's int8 domain (tsta_psa_reference_exact)
 }
 
 extern "C" void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs)
@@ -1339,6 +1341,6 @@ extern "C" int tsta_psa_align_batch(tsta_engine* eng, const tsta_params* p, int6
         group.push_back(J); group_idx.push_back(k); used += need;
     }
     if (rc == TSTA_OK) rc = flush();
-    if (rc != TSTA_OK) tsta_alignments_free(out, n_pairs);
-    return rc;
+    if (rc != TSTA_OK) { tsta_alignments_free(out, n_pairs); return rc; }
+    return psa_reference_warning(e, p);
 }

@@ -82,7 +82,7 @@ int main(int argc, char* argv[])
     int64_t alen = 0;
     rc = tsta_psa_align(eng, &prm, (const uint8_t*)s1->data, (int64_t)s1->length, (const uint8_t*)s2->data,
                         (int64_t)s2->length, &ms, &row_a, &row_b, &alen);
-    if (rc != TSTA_OK) return fail(eng, rc, "tsta_psa_align");
+    if (TSTA_FAILED(rc)) return fail(eng, rc, "tsta_psa_align");
     FILE* fptr = fopen(output, "w");                             /* psa.c:641, 512-515 */
     if (!fptr) { fprintf(stderr, "cannot open %s\n", output); return 1; }
     fputs(">1\n", fptr); fputs(row_a, fptr); fputs("\n>2\n", fptr); fputs(row_b, fptr);
@@ -99,9 +99,12 @@ int main(int argc, char* argv[])
         int32_t l1 = (int32_t)s1->length, l2 = (int32_t)s2->length;
         rc = tsta_psa_score_batch(eng, &prm, 1, both, (int64_t)tot, &off1, &l1, &off2, &l2, &ms);
         free(both);
-        if (rc != TSTA_OK) return fail(eng, rc, "tsta_psa_score_batch");
+        if (TSTA_FAILED(rc)) return fail(eng, rc, "tsta_psa_score_batch");
     }
 #endif
+    /* rc > 0: valid result, but for this scoring the reference binary's own output is a property of its int8 encoding (SIMD width,
+     * -W): stdout and the output file keep the reference's format, the note goes to stderr */
+    if (rc == TSTA_WARN_REFERENCE_UNDEFINED) fprintf(stderr, "warning: %s\n", tsta_last_warning(eng));
     printf("maxsorce=%d\n", ms);                                 /* psa.c:666 */
     /* every output is written and closed: no need to walk the runtime's exit handlers (cli_common.h) */
     cli_quick_exit(0);
