@@ -63,20 +63,47 @@ def make_shard(n_pairs, length, seed, device):
     return ms(n_pairs, length, seed, device, related=0.0)
 
 
+TRACE_FORMS = {0: "psa_trace_tile_kernel<2,true,false> (one launch per tile diagonal)", 1: "psa_trace_tile_kernel<2,true,true> (single launch)",
+               2: "psa_trace_quad_kernel<2>", 3: "psa_trace_split_kernel<2,false> (solver bands + emitter tiles)",
+               4: "psa_trace_split_kernel<2,true> (solver bands + emitter tiles)", 5: "psa_trace_packed dataflow"}
+
+
+def _build_hash():
+    """The 16 hex digits of the library this process runs (tsta_build_info: SHA-256 over the kernel sources)."""
+    try:
+        return tsta_amd.lib().tsta_build_info().decode().split()[1]
+    except Exception:
+        return None
+
+
 def _traffic(key):
-    """HBM bytes per launch of a config's dominant kernel from the committed PMC passes (profiles/traffic_configs.json, made by
-    tools/collect_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of this file; gfx950 correction applied there) or None."""
+    """-> (HBM bytes per launch of a config's dominant kernel, provenance).  The bytes come from COMMITTED PMC passes
+    (profiles/traffic_configs.json, made by tools/collect_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of this file; gfx950
+    correction applied there), not from this run: the provenance names the file and the build it was measured on, and the value is
+    dropped (None) when that build is not the one running now."""
+    src = {"file": "profiles/traffic_configs.json", "measured_on_build": None, "this_build": _build_hash()}
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))
-        return float(t[key]["hbm_bytes_per_launch"])
+        src["measured_on_build"] = t.get("_build")
+        v = float(t[key]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
-        return None
+        return None, src
+    if src["measured_on_build"] != src["this_build"]:
+        src["dropped"] = "PMC passes were made on another build of the kernels"
+        return None, src
+    return v, src
+
+
+def _roofline_traffic(d, key):
+    d["traffic"], d["traffic_source"] = _traffic(key)
+    return d
 
 
 def _trace_roofline(cells, kernel_ms, kernel, traffic_key=None):
     ach = cells / (kernel_ms * 1e-3) / 1e9
+    tr, tsrc = _traffic(traffic_key) if traffic_key else (None, None)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": _traffic(traffic_key) if traffic_key else None,
+            "traffic": tr, "traffic_source": tsrc,
             "kernel": kernel, "note": "SURVEY 8(d) trace mode: cells x 1 B of packed trace / kernel time (fill + on-device walk) against "
                                       "the 8 TB/s HBM-write roof; the binding resource is the chain of dependent steps (one pair) or "
                                       "VALU issue (batches), DESIGN.md section 4"}
@@ -110,7 +137,8 @@ def config2(eng, cores=None, reps=5, verify=True, cpu=True, seed=20252):
     out = {"config": "#2: 1024 pairs 5 kbp x 5 kbp random DNA, score only, inputs HBM-resident", "kernel_ms": t,
            "wall_ms": float(np.median(wall)), "launches": nl, "gcups": cells / t / 1e6,
            "roofline": {"bound": "hbm", "achieved": alg / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("psa_score_bands_kernel"), "kernel": "psa_score_bands_kernel<16,true>",
+                        "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("psa_score_bands_kernel")[0],
+                        "traffic_source": _traffic("psa_score_bands_kernel")[1], "kernel": "psa_score_bands_kernel<16,true>",
                         "valu_frac_at_4p4_ops_per_cell": cells * 4.4 / (t * 1e-3) / 7.86432e13,
                         "note": "score mode: algorithmic bytes (len_a + len_b + 4 per pair), ~0 by construction (SURVEY 8d); the kernel "
                                 "is VALU-issue-bound and, at this size, by the band pipeline's ramp (5 bands of 1 024 rows x 79 tiles per couple)"}}
@@ -187,12 +215,16 @@ def config3(eng, cores=None, verify=True, cpu=True):
         ks.append(eng.last_kernel_ms()[0])
     assert (ms, ra, rb) == (ms2, ra2, rb2)
     k2, wall2 = float(np.median(ks)), float(np.median(walls))
+    form = eng.stat("last_trace_form")                     # what actually ran (the label below is derived from it)
     cells = float(len(x)) * len(y)
     out = {"config": "#3: one %d x %d pair with traceback (1 B/cell packed trace in HBM: %.1f GB)" % (len(x), len(y), cells / 1e9),
            "maxsorce": ms, "alignment_len": len(ra), "kernel_ms_first": k1, "kernel_ms": k2, "launches": nl,
            "wall_ms_first": wall1 * 1e3, "wall_ms": wall2, "gcups": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e6,
-           "reruns": eng.stat("single_launch_reruns"),
-           "roofline": _trace_roofline(cells, k2, "psa_trace_split_kernel<2,true> (solver bands + emitter tiles) + psa_walk_kernel<2,32>", "psa_trace_split_kernel")}
+           "reruns": eng.stat("single_launch_reruns"), "trace_form": form,
+           "roofline": _trace_roofline(cells, k2, TRACE_FORMS.get(form, "form %d" % form) + " + psa_walk_kernel<2,32>",
+                                       "psa_trace_split_kernel" if form in (3, 4) else None)}
+    if out["reruns"]:
+        out["flag"] = "a single launch was abandoned and run again through the launch pipeline: kernel_ms is not the single-launch form's"
     if verify:
         data = b">1\n" + ra + b"\n>2\n" + rb                 # what TSTA_psa writes (psa.c:512-516)
         ok = (ms == g["maxsorce"] and len(data) == g["size"] and hashlib.md5(data).hexdigest() == g["md5"] and
@@ -265,7 +297,7 @@ def config4(eng, cores=None, verify=True, cpu=True):
            "kernel_ms": tot_fw, "fill_kernel_ms": tot_fill, "walk_kernel_ms": tot_fw - tot_fill, "wall_ms": tot_wall,
            "gcups": tot_cells / tot_fw / 1e6, "gcups_fill": tot_cells / tot_fill / 1e6, "reruns": eng.stat("single_launch_reruns"),
            "roofline": {"bound": "hbm", "achieved": byts / (tot_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": byts / (tot_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("poa_dataflow_kernel"), "kernel": "poa_dataflow_kernel",
+                        "frac": byts / (tot_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": _traffic("poa_dataflow_kernel")[0], "traffic_source": _traffic("poa_dataflow_kernel")[1], "kernel": "poa_dataflow_kernel",
                         "us_per_row": tot_fill * 1e3 / rows,
                         "note": "SURVEY 8(d) POA: 3 B/cell trace + 8 B/cell rows against 8 TB/s, and the time per graph row: the fill "
                                 "is the chain of its rows (5 000 columns are 40 workgroups wide), i.e. latency-bound, DESIGN.md section 5"}}

@@ -160,7 +160,9 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
  * and tsta_psa_score_batch_dev_status() (synchronises `stream`) returns TSTA_ERR_INTERNAL.  No path returns success with a
  * wrong number.  Option "test_abandon" forces the event in tests. */
 int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
-/* Counters of an engine: "single_launch_reruns".  TSTA_ERR_INVALID_ARG for an unknown key. */
+/* Counters of an engine: "single_launch_reruns"; "last_trace_form" = how the last tsta_psa_align[_batch] group was filled (0 one
+ * launch per tile diagonal, 1 single launch with tiles through memory, 2 LDS-linked quads, 3 / 4 solver bands + emitter tiles
+ * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form).  TSTA_ERR_INVALID_ARG for an unknown key. */
 int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);
 
 /* 2-bit packed input for pure-ACGT batches: a quarter of the host memory, PCIe traffic and input
@@ -228,10 +230,15 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device);
  *   (4) the last block is padded and W max(|E|, M) + |O| >= 60: one byte lane's W padding columns ('N', readseq) shift a row beyond
  *       the trackers' cutoff between the two passes (measured: -W 32 at the default scoring; the bound is empirical).
- * There the fill runs — (1), (2), (4) at once, (3) as a second run after the plain fill has seen the distance — in the reference's
+ *   (5) the SCORING lies outside M >= 1, X < M, E <= -1, O <= 0, W max(|E|, M) + |O| + |X| < 64 (W = "poa_ref_block" / 64): W columns
+ *       of matches / gap extensions, a gap open and a mismatch no longer stay inside the reference's saturating int8 trackers and
+ *       their cutoff at 60; an empirical rule (2 168 scanned points, smallest left-hand side with a difference: 71;
+ *       tests/golden/msa_domain_golden.json keeps 178 of them with the compiled reference's output) — tsta_poa_reference_exact.
+ * There the fill runs — (1), (2), (4), (5) at once, (3) as a second run after the plain fill has seen the distance — in the reference's
  * own arithmetic and in the blocking of its AVX512 build at -W = "poa_ref_block" / 64 (option "poa_ref_arith"), and the result is
  * what that build prints, byte for byte (all 200 outputs of tests/golden/msa_n_golden.json, all of msa_w_golden.json): status
- * TSTA_OK.  Only where that path cannot run ("poa_ref_arith" = 0, "poa_ref_block" not 64 x 1..32, in-degree x W beyond the LDS)
+ * TSTA_OK.  Only where that path cannot run ("poa_ref_arith" = 0, "poa_ref_block" not 64 x 1..32, in-degree x W beyond the LDS, its
+ * 2 B per cell of rows beyond the free device memory, a scoring parameter outside int8)
  * the call returns the plain DP ('N' rule applied consistently) with TSTA_WARN_REFERENCE_UNDEFINED and says which case it was.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct tsta_dag_csr {
@@ -245,6 +252,11 @@ typedef struct tsta_dag_csr {
 int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,
                   int32_t n, int8_t* source, int8_t* esource, int8_t* fsource, int32_t* lastscore,
                   int32_t* best_sink);
+
+/* 1: for this scoring the reference's POA fill at block length ref_block (= 64 x its -W; option "poa_ref_block") is the plain DP on
+ * every input outside cases (1)-(4) above, i.e. the fast kernels serve the call; 0: case (5), the call runs in the reference's
+ * arithmetic; < 0: tsta_status.  why (may be NULL) receives the reason ("" for 1).  Pure host arithmetic. */
+int tsta_poa_reference_exact(const tsta_params* p, int32_t ref_block, char* why, size_t why_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * POA fill + traceback walk  ==  control() up to and including the WALK of node_fuse (c-t-simd.c:737-957), i.e.

@@ -268,3 +268,58 @@ def test_sixth_distinct_character_in_a_column_is_an_error_not_a_crash(oracle_dri
             assert r.returncode == 0, r.stderr
         else:
             assert r.returncode != 0 and b"sixth distinct character" in r.stderr
+
+
+# ---- the SCORING domain of the fast POA kernels (round 4) ---------------------------------------------------------
+# tests/golden/msa_domain_golden.json (make_msa_domain_golden.py): the compiled reference at the case's -W on both sides of the
+# routing rule `tsta_poa_reference_exact` (poa_fill.hip: poa_scoring_is_plain_dp).  On the rule's fast side the plain-DP
+# restatement must equal the reference (so the fast kernels may serve the call); the int8 restatement must equal it everywhere
+# (so K4e may serve the rest).
+import tsta_amd  # noqa: E402
+from tests.golden.make_msa_domain_golden import domain_case_seqs  # noqa: E402
+
+with open(os.path.join(util.GOLDEN_DIR, "msa_domain_golden.json")) as _f:
+    D_GOLDEN = json.load(_f)
+
+
+def _fast(c):
+    return tsta_amd.poa_reference_exact(ref_block=64 * c["W"], **c["scoring"])[0]
+
+
+def test_msa_domain_rule_known_points():
+    assert tsta_amd.poa_reference_exact() == (True, "")                                   # defaults at -W 10
+    assert tsta_amd.poa_reference_exact(M=2, X=-3, E=-2, O=-4)[0] and tsta_amd.poa_reference_exact(M=1, X=-1, E=-1, O=0)[0]
+    assert not tsta_amd.poa_reference_exact(M=5, X=-4, E=-1, O=-10)[0]                     # 10 x 5 + 10 + 4 = 64
+    assert tsta_amd.poa_reference_exact(ref_block=64 * 27)[0] and not tsta_amd.poa_reference_exact(ref_block=64 * 28)[0]
+    for kw in (dict(M=0), dict(X=2), dict(E=0), dict(O=1), dict(M=200), dict(X=-129)):
+        ok, why = tsta_amd.poa_reference_exact(**kw)
+        assert not ok and why
+    n_fast = sum(_fast(c) for c in D_GOLDEN)
+    assert len(D_GOLDEN) >= 150 and n_fast >= 80 and len(D_GOLDEN) - n_fast >= 60
+
+
+@pytest.mark.parametrize("idx", range(len(D_GOLDEN)))
+def test_msa_domain_restatements_equal_the_reference(oracle_driver, tmp_path, idx):
+    c = D_GOLDEN[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, domain_case_seqs(c))
+    sc = c["scoring"]
+    assert _run_blocked(oracle_driver, fa, out, sc, -c["W"]) == c["md5"], ("int8 restatement", c["W"], sc)
+    if _fast(c):
+        r = subprocess.run([oracle_driver, str(sc["M"]), str(sc["X"]), str(sc["E"]), str(sc["O"]), fa, out], capture_output=True, timeout=600)
+        assert r.returncode == 0
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["md5"], ("plain DP on the rule's fast side", c["W"], sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(D_GOLDEN)))
+def test_msa_domain_cli_on_gpu(tmp_path, idx):
+    c = D_GOLDEN[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, domain_case_seqs(c))
+    sc = c["scoring"]
+    r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O", str(sc["O"]),
+                        "-T", "4", "-W", str(c["W"]), "-i", fa, "-o", out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["md5"], (c["W"], sc)
+    assert r.stderr.decode().count("warning:") == 0

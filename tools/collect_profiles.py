@@ -66,9 +66,20 @@ def pmc_by_kernel(sub, counter):
     return acc
 
 
+def build_of_run():
+    """16 hex digits of the library the profiled run used: <run>/build_info.txt (written on the GPU box by the profile script) or,
+    failing that, the tree's tsta_amd/lib/BUILD_INFO (valid only while the sources have not changed since the run)."""
+    for f in (os.path.join(base, "build_info.txt"), os.path.join(os.path.dirname(out), "tsta_amd", "lib", "BUILD_INFO")):
+        if os.path.exists(f):
+            w = open(f).read().split()
+            if len(w) >= 2:
+                return w[1]
+    return None
+
+
 cf, cw = pmc_by_kernel("prof_cfg_fetch", "FETCH_SIZE"), pmc_by_kernel("prof_cfg_write", "WRITE_SIZE")
 if cf and cw:
-    tc = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench_configs.py 2 3 4 5t; "
+    tc = {"_build": build_of_run(), "_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench_configs.py 2 3 4 5t; "
                   "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, "
                   "median over the launches of that kernel in the run; poa_dataflow_kernel: mean x 4 = one set of the README example's four "
                   "fills (the unit configs['4'].roofline.achieved is quoted on)"}

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "tsta_multi_create", "tsta_multi_destroy", "tsta_multi_device_count", "tsta_multi_engine", "tsta_multi_last_error",
     "tsta_multi_set_option", "tsta_shard_bounds", "tsta_psa_score_batch_multi", "tsta_psa_align_batch_multi",
     "tsta_build_info", "tsta_device_uuid", "tsta_last_warning", "tsta_psa_score_batch_dev_status", "tsta_engine_stat",
-    "tsta_psa_reference_exact",
+    "tsta_psa_reference_exact", "tsta_poa_reference_exact",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.tsta_device_uuid.restype = C.c_int; L.tsta_device_uuid.argtypes = [C.c_int, C.c_char_p]
         L.tsta_shard_bounds.restype = C.c_int; L.tsta_shard_bounds.argtypes = [i64, vp, vp, C.c_int, vp]
         L.tsta_psa_reference_exact.restype = C.c_int; L.tsta_psa_reference_exact.argtypes = [C.POINTER(Params), C.c_char_p, C.c_size_t]
+        L.tsta_poa_reference_exact.restype = C.c_int; L.tsta_poa_reference_exact.argtypes = [C.POINTER(Params), i32, C.c_char_p, C.c_size_t]
         L.tsta_multi_create.restype = C.c_int; L.tsta_multi_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.tsta_multi_destroy.restype = None; L.tsta_multi_destroy.argtypes = [vp]
         L.tsta_multi_device_count.restype = C.c_int; L.tsta_multi_device_count.argtypes = [vp]
@@ -191,6 +192,16 @@ def psa_reference_exact(params=None, **kw):
     rc = lib().tsta_psa_reference_exact(C.byref(params), buf, len(buf))
     if rc < 0:
         raise TstaError("tsta_psa_reference_exact: %s" % lib().tsta_strerror(rc).decode())
+    return bool(rc), buf.value.decode()
+
+
+def poa_reference_exact(params=None, ref_block=640, **kw):
+    """tsta_poa_reference_exact: (plain_dp, why) — do the fast POA kernels compute what the reference prints for this scoring?"""
+    params = params or Params(**kw)
+    buf = C.create_string_buffer(512)
+    rc = lib().tsta_poa_reference_exact(C.byref(params), int(ref_block), buf, len(buf))
+    if rc < 0:
+        raise TstaError("tsta_poa_reference_exact: %s" % lib().tsta_strerror(rc).decode())
     return bool(rc), buf.value.decode()
 
 

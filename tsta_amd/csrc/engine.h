@@ -34,6 +34,8 @@ struct Engine {
     bool      ref8_feasible = false;  // the last POA fill could have run through poa_ref8.hip (-W in range, LDS, memory)
     bool      force_ref8 = false;     // transient: run the next POA fill through poa_ref8.hip if it can be (second run after a spread beyond the trackers)
     unsigned* poa_status = nullptr;   // device word the last POA fill's waits report into (dataflow form), or null
+    int       last_trace_form = 0;    // how the last trace fill ran: 0 launch per tile diagonal, 1 single launch (tiles through memory), 2 LDS-linked quads,
+                                      // 3 / 4 solver bands + emitter tiles (generic / pure-ACGT table), 5 coupled pairs in dataflow form
     int align_calls = 0;   // tsta_psa_align_batch calls so far (its workspace cap grows with them)
 
     DevBuf counter;      // ticket counters / flags (zeroed per launch)
@@ -56,6 +58,7 @@ struct Engine {
     // small blocking copies ON THE ENGINE'S STREAM (a plain hipMemcpy would bring up the process's null stream: ~15 ms the first time)
     int  copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, const char* what);
     int  reserve(DevBuf& b, size_t bytes, const char* what, bool growing = false);
+    void forget_status_in(const DevBuf& b);   // nulls psa_status / poa_status when they point into a buffer about to be freed
     void timing_begin(hipStream_t s);
     void timing_end(hipStream_t s);
 };

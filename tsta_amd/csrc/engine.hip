@@ -36,11 +36,21 @@ int Engine::check(hipError_t e, const char* what)
     return e == hipErrorOutOfMemory ? TSTA_ERR_OOM : TSTA_ERR_HIP;
 }
 
+// the status words of the last single-launch fills live inside workspaces: a buffer that is freed (or regrown) takes them along,
+// and a later tsta_psa_score_batch_dev_status() / walker must not read through the stale pointer
+void Engine::forget_status_in(const DevBuf& b)
+{
+    const char* lo = static_cast<const char*>(b.p); const char* hi = lo + b.bytes;
+    auto inside = [&](const void* q) { return q && static_cast<const char*>(q) >= lo && static_cast<const char*>(q) < hi; };
+    if (inside(psa_status)) psa_status = nullptr;
+    if (inside(poa_status)) poa_status = nullptr;
+}
+
 int Engine::reserve(DevBuf& b, size_t bytes, const char* what, bool growing)
 {
     if (b.bytes >= bytes && b.p) return TSTA_OK;
     const bool regrow = b.p != nullptr;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) { forget_status_in(b); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     // `growing`: the caller's need rises from call to call (the POA graph gains nodes with every sequence of an MSA), and a
     // device allocation costs ~35 ms per GB: a buffer that had to grow once gets 50 % headroom instead of 12.5 %
     size_t want = bytes + ((growing && regrow) ? bytes / 2 : bytes / 8) + 256;
@@ -254,7 +264,7 @@ int tsta_engine_release_workspaces(tsta_engine* eng)
     // everything but the small counter block (ticket words, self-test / result scalars)
     for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
                             &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) { e->forget_status_in(*b); (void)hipFree(b->p); }
         b->p = nullptr; b->bytes = 0;
     }
     return TSTA_OK;
@@ -292,6 +302,7 @@ int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
     if (!eng || !key || !value) return TSTA_ERR_INVALID_ARG;
     const Engine* e = reinterpret_cast<const Engine*>(eng);
     if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
+    if (!strcmp(key, "last_trace_form")) { *value = e->last_trace_form; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;
 }
 

@@ -55,11 +55,14 @@ __device__ __forceinline__ void wait_progress(const int* word, int need, unsigne
         const int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (cur >= need) break;
         const int far = (need - cur) >> 7;                      // 64-step blocks take >= 12 us: 3.4 us of sleep per 128 steps is safe
+        // once any wave has given up, nobody waits any more and the launch drains quickly: looked at before every LONG sleep (a far
+        // wait sleeps up to 108 us per spin: looking only every 256 spins let every later wait of an abandoned launch take ~28 ms to
+        // drain) and every 256 spins when near (~50 ns per spin; looking every 16 cost config #2 35 %)
+        if ((far > 0 || (spins & 255) == 255) &&
+            __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         if (far > 0) { for (int i = 0; i < min(far, 32); ++i) __builtin_amdgcn_s_sleep(127); }
         else __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 17)) { if (lane == 0) atomicOr(status, 1u); break; }      // far: ~14 s; near: ~0.1 s
-        // once any wave has given up, nobody waits any more: the launch drains quickly
-        if ((spins & 255) == 0 && __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     }
     // compiler-only barrier: the sc1 loads of the entries that follow (other addresses, relaxed) must not be hoisted above
     // the final poll.  The hardware ordering comes from the s_waitcnt on the poll's result, which the loop exit depends on.

@@ -798,11 +798,44 @@ void launch_poa_best(const PoaArgs& A, hipStream_t s) { hipLaunchKernelGGL(poa_b
 // padded columns shift a row beyond the trackers' cutoff between the two passes.  That last bound is empirical: over 2 x 3 x 8
 // fixed and 60 random (graph, cut, scoring, W) combinations the int8 restatement left the plain DP first at
 // W max(|E|, M) + |O| = 68 (default scoring: -W 32); 60 is used.
+//
+// (5) The SCORING itself (round 4).  The reference holds row differences in saturating int8, cuts a predecessor off once the row
+// has risen 60 above it and guesses the state at the start of every byte lane (c-t-simd.c:196-261,357-404,438-447): its output is
+// the plain DP only while W columns of matches / gap extensions, a gap open and a mismatch together stay well inside that range.
+// Empirical rule (tests/golden/make_msa_domain_golden.py: 2 168 scanned (scoring, -W) points, smallest left-hand side with a
+// difference: 71; 178 of them kept as fixtures with the compiled reference's output):
+//     plain DP  iff  M >= 1, X < M, E <= -1, O <= 0, all four in int8  and  W max(|E|, M) + |O| + |X| < 64
+// Everything else goes through the reference's own arithmetic (K4e reproduced the compiled reference on every scanned point,
+// including M = X, M = 0 and E = 0); scorings outside int8 cannot (mm_set1_epi8 truncates them): plain DP + warning.
+static bool poa_scoring_fits_int8(const tsta_params* p)
+{
+    for (int v : {p->M, p->X, p->E, p->O}) if (v < -128 || v > 127) return false;
+    return true;
+}
+
+bool poa_scoring_is_plain_dp(const tsta_params* p, int64_t L, char* why, size_t cap)
+{
+    const int64_t W = L / 64;
+    const long long q = W * std::max(std::abs((long long)p->E), std::abs((long long)p->M)) + std::abs((long long)p->O) + std::abs((long long)p->X);
+    const bool signs = p->M >= 1 && p->X < p->M && p->E <= -1 && p->O <= 0;
+    const bool ok = signs && poa_scoring_fits_int8(p) && q < 64;
+    if (why && cap) {
+        if (ok) why[0] = 0;
+        else if (!poa_scoring_fits_int8(p)) snprintf(why, cap, "M=%d X=%d E=%d O=%d do not fit the reference's int8 lanes (mm_set1_epi8 truncates them)", p->M, p->X, p->E, p->O);
+        else if (!signs) snprintf(why, cap, "M=%d X=%d E=%d O=%d: outside M >= 1, X < M, E <= -1, O <= 0, where the reference's tie-breaking and lazy passes are "
+                                  "not those of the plain DP", p->M, p->X, p->E, p->O);
+        else snprintf(why, cap, "M=%d X=%d E=%d O=%d at -W %lld: W max(|E|, M) + |O| + |X| = %lld >= 64, beyond what the reference's saturating "
+                      "int8 trackers and their cutoff at 60 hold (c-t-simd.c:196-261,370-404)", p->M, p->X, p->E, p->O, (long long)W, q);
+    }
+    return ok;
+}
+
 static bool poa_needs_reference_arithmetic(const Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n)
 {
     const int64_t L = e->opt_poa_ref_block;
     if (memchr(seq, 'N', (size_t)n) != nullptr) return true;
     if (((int64_t)n + L - 1) / L > ((int64_t)V + L - 1) / L) return true;
+    if (!poa_scoring_is_plain_dp(p, L, nullptr, 0)) return true;
     return (n % L) != 0 && (L / 64) * std::max(std::abs(p->E), std::abs(p->M)) + std::abs(p->O) >= 60;
 }
 
@@ -827,6 +860,9 @@ static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const u
     else if (spread > limit)
         snprintf(e->warn, sizeof(e->warn), "two predecessor rows of one node lie %d apart (limit %d): beyond the reference's saturating offset "
                  "tracker (c-t-simd.c:196-261,370-404), its own output may deviate from the DP computed here", spread, limit);
+    else if (char why[256]; !poa_scoring_is_plain_dp(p, L, why, sizeof(why)))
+        snprintf(e->warn, sizeof(e->warn), "scoring outside the domain where the reference's POA fill is the plain DP (%s): its own output there is a "
+                 "property of its int8 arithmetic and of -W; this result is the plain DP", why);
     else if (poa_needs_reference_arithmetic(e, p, V, seq, n))
         snprintf(e->warn, sizeof(e->warn), "the sequence is padded by %lld columns at -W %lld: one lane's padded columns can shift a row beyond the "
                  "cutoff of the reference's offset trackers between its two passes (c-t-simd.c:370-404), its own output may deviate from the "
@@ -905,13 +941,58 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
         for (int k = dag->pred_off[r], x = 0; k < dag->pred_off[r + 1] && x < 4; ++k, ++x) ptab[(size_t)r * 4 + x] = dag->pred[k];
     const size_t meta = (size_t)(V + 1) * 4 + (size_t)std::max(npred, 1) * 8 + (size_t)V * 4 + (size_t)V * 2 + (size_t)n + 64 + (size_t)V * 16 + 16;
     const size_t rows_bytes = (size_t)nslots * pitch * sizeof(int);
+
+    // K4e (poa_ref8.hip): inputs on which the reference's output is a property of its int8 arithmetic and blocking are filled in
+    // that arithmetic, at -W = poa_ref_block / 64 (poa_needs_reference_arithmetic; option "poa_ref_arith": 0 never, 1 those
+    // inputs, 2 every fill), where W <= 32, the per-predecessor lane state fits the LDS and its rows (2 B per cell) fit the
+    // device NEXT TO the other workspaces of the call.  Decided here, before anything is reserved: the row buffer
+    // is then reserved ONCE for whichever path runs, and a K4e whose rows cannot be had falls back to the plain DP + warning
+    // instead of failing the call.
+    e->poa_blocked_w = 0;
+    e->ref8_feasible = false;
+    bool use_ref8 = false;
+    PoaRef8Args B;
+    size_t ref8_rows_b = 0, ref8_aux_b = 0;
+    if (e->opt_poa_n_blocked != 0 && e->opt_poa_ref_block % 64 == 0 && e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32) {
+        B.W = e->opt_poa_ref_block / 64; B.Wq = (B.W + 3) / 4;
+        const int64_t Lb = 64 * (int64_t)B.W;
+        B.nblk = (int)((n + Lb - 1) / Lb);
+        B.nrowblk = (int)((V + Lb - 1) / Lb);
+        B.maxtag = B.nblk - 1;                                 // c-t-simd.c:987-1001 (length1 = nblk L, length2 = nrowblk L)
+        if (B.nblk >= B.nrowblk) { B.fmaxtag = B.nrowblk - 1; B.lmaxtag = B.nblk - 1; }
+        else { B.fmaxtag = B.nblk - 1; B.lmaxtag = B.nrowblk - 1; }
+        B.maxp = 1;
+        for (int r = 0; r < V; ++r) B.maxp = std::max(B.maxp, dag->pred_off[r + 1] - dag->pred_off[r]);
+        ref8_rows_b = (size_t)V * B.nblk * 2 * B.Wq * 64 * sizeof(int) + 64;
+        ref8_aux_b = ((size_t)V * (B.nblk + 1) + (size_t)V + (size_t)V * B.maxp + (size_t)B.nblk + 64 + 16) * sizeof(int) + 64;
+        size_t free_b = 0, total_b = 0;
+        if ((rc = e->check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo")) != TSTA_OK) return rc;
+        // what the call may take: free memory + what the engine already holds in the buffers it is about to (re)size, minus the
+        // trace arrays and the small buffers every path needs, with 10 % to spare
+        const size_t held = e->rows.bytes + e->scratch.bytes + e->trace.bytes;
+        const size_t others = (want_trace ? 3 * (size_t)V * tpitch : 0) + meta + (size_t)V * (nchunks + 1) + ((size_t)64 << 20);
+        const size_t room = (size_t)((double)(free_b + held) * 0.9);
+        e->ref8_feasible = poa_scoring_fits_int8(p) && poa_ref8_lds_bytes(B.maxp, B.Wq) <= ((size_t)152 << 10) && ref8_rows_b + ref8_aux_b + others <= room;
+        use_ref8 = e->ref8_feasible && (e->opt_poa_n_blocked == 2 || e->force_ref8 || poa_needs_reference_arithmetic(e, p, V, seq, n));
+    }
+    const size_t plain_rows_b = 2 * rows_bytes;
+    const size_t plain_scratch_b = 5 * (size_t)V * (nchunks + 1) * 4 + 64 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64;
     if ((rc = e->reserve(e->in_meta, meta + 64, "hipMalloc(dag)", true)) ||
-        (rc = e->reserve(e->rows, 2 * rows_bytes, "hipMalloc(poa rows)", true)) ||
         (rc = e->reserve(e->out_scores, (size_t)V * 4 + 64, "hipMalloc(lastscore)", true)) ||
-        (rc = e->reserve(e->scratch, 5 * (size_t)V * (nchunks + 1) * 4 + 64 + ((size_t)2 * (nchunks + nrb) + nchunks + 64) * 4 + 64, "hipMalloc(poa carry)", true)) ||
         (rc = e->reserve(e->scratch2, (size_t)V * (nchunks + 1) + 64, "hipMalloc(poa flags)", true)))
         return rc;
     if (want_trace && (rc = e->reserve(e->trace, 3 * (size_t)V * tpitch + 64, "hipMalloc(poa trace)", true))) return rc;
+    if (use_ref8) {
+        if ((rc = e->reserve(e->rows, std::max(plain_rows_b, ref8_rows_b), "hipMalloc(poa rows, reference arithmetic)", true)) ||
+            (rc = e->reserve(e->scratch, std::max(plain_scratch_b, ref8_aux_b), "hipMalloc(poa sums, reference arithmetic)", true))) {
+            if (rc != TSTA_ERR_OOM) return rc;
+            use_ref8 = false; e->ref8_feasible = false;          // (the estimate above was wrong: plain DP, and the call will say so)
+        }
+    }
+    if (!use_ref8 &&
+        ((rc = e->reserve(e->rows, plain_rows_b, "hipMalloc(poa rows)", true)) ||
+         (rc = e->reserve(e->scratch, plain_scratch_b, "hipMalloc(poa carry)", true))))
+        return rc;
 
     char* m = reinterpret_cast<char*>(e->in_meta.p);
     int* d_off = reinterpret_cast<int*>(m);
@@ -951,52 +1032,26 @@ static int poa_run_on_device(Engine* e, const tsta_params* p, const tsta_dag_csr
     A.M = p->M; A.X = p->X; A.E = p->E; A.O = p->O;
     A.links = 0;
 
-    // K4e (poa_ref8.hip): inputs on which the reference's output is a property of its int8 arithmetic and blocking are filled in
-    // that arithmetic, at -W = poa_ref_block / 64 (poa_needs_reference_arithmetic; option "poa_ref_arith": 0 never, 1 those
-    // inputs, 2 every fill), where W <= 32 and the per-predecessor lane state fits the LDS
-    e->poa_blocked_w = 0;
-    e->ref8_feasible = false;
-    if (e->opt_poa_n_blocked != 0 && e->opt_poa_ref_block % 64 == 0 && e->opt_poa_ref_block / 64 >= 1 && e->opt_poa_ref_block / 64 <= 32) {
-        PoaRef8Args B;
-        B.W = e->opt_poa_ref_block / 64; B.Wq = (B.W + 3) / 4;
-        const int64_t Lb = 64 * (int64_t)B.W;
-        B.nblk = (int)((n + Lb - 1) / Lb);
-        B.nrowblk = (int)((V + Lb - 1) / Lb);
-        B.maxtag = B.nblk - 1;                                 // c-t-simd.c:987-1001 (length1 = nblk L, length2 = nrowblk L)
-        if (B.nblk >= B.nrowblk) { B.fmaxtag = B.nrowblk - 1; B.lmaxtag = B.nblk - 1; }
-        else { B.fmaxtag = B.nblk - 1; B.lmaxtag = B.nrowblk - 1; }
-        B.maxp = 1;
-        for (int r = 0; r < V; ++r) B.maxp = std::max(B.maxp, dag->pred_off[r + 1] - dag->pred_off[r]);
-        const size_t rows_b = (size_t)V * B.nblk * 2 * B.Wq * 64 * sizeof(int);
-        const size_t aux_ints = (size_t)V * (B.nblk + 1) + (size_t)V + (size_t)V * B.maxp + (size_t)B.nblk + 64 + 16;
-        e->ref8_feasible = poa_ref8_lds_bytes(B.maxp, B.Wq) <= ((size_t)152 << 10) && rows_b <= ((size_t)32 << 30);
-        if (e->ref8_feasible &&
-            (e->opt_poa_n_blocked == 2 || e->force_ref8 || poa_needs_reference_arithmetic(e, p, V, seq, n))) {
-            // (a failed allocation is an error, not a reason to go on with the other kernels: their row pointers above may
-            // refer to a buffer this reservation has just replaced)
-            if ((rc = e->reserve(e->rows, rows_b + 64, "hipMalloc(poa rows, reference arithmetic)", true)) ||
-                (rc = e->reserve(e->scratch, aux_ints * sizeof(int) + 64, "hipMalloc(poa sums, reference arithmetic)", true)))
-                return rc;
-            B.A = A;
-            B.rows = reinterpret_cast<int*>(e->rows.p);
-            B.simple = reinterpret_cast<int*>(e->scratch.p);
-            B.first_col = B.simple + (size_t)V * (B.nblk + 1);
-            B.f0 = B.first_col + V;
-            int* d_sync = B.f0 + (size_t)V * B.maxp;
-            B.ticket = reinterpret_cast<unsigned*>(d_sync); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.prog = d_sync + 64;
-            B.test_abandon = e->opt_test_abandon; B.k_fixed = -1;
-            if ((rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)B.nblk + 64) * sizeof(int), s), "hipMemsetAsync(poa reference arithmetic)")) ||
-                (rc = e->check(hipMemsetAsync(A.best, 0, 16 * sizeof(int), s), "hipMemsetAsync(poa best)"))) return rc;
-            e->timing_begin(s);
-            const bool single = e->opt_poa_dataflow != 0;       // (0: the second run after an abandoned single launch)
-            const int nl = launch_poa_ref8(B, single, s);
-            if (nl < 0) { e->set_error("poa_ref8: %zu bytes of LDS refused", poa_ref8_lds_bytes(B.maxp, B.Wq)); return TSTA_ERR_INTERNAL; }
-            hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
-            e->n_launches = nl + 1;
-            e->poa_status = single ? B.status : nullptr;
-            e->poa_blocked_w = B.W;
-            return e->check(hipGetLastError(), "poa_fill (reference arithmetic) launch");
-        }
+    if (use_ref8) {
+        B.A = A;
+        B.rows = reinterpret_cast<int*>(e->rows.p);
+        B.simple = reinterpret_cast<int*>(e->scratch.p);
+        B.first_col = B.simple + (size_t)V * (B.nblk + 1);
+        B.f0 = B.first_col + V;
+        int* d_sync = B.f0 + (size_t)V * B.maxp;
+        B.ticket = reinterpret_cast<unsigned*>(d_sync); B.status = reinterpret_cast<unsigned*>(d_sync + 1); B.prog = d_sync + 64;
+        B.test_abandon = e->opt_test_abandon; B.k_fixed = -1;
+        if ((rc = e->check(hipMemsetAsync(d_sync, 0, ((size_t)B.nblk + 64) * sizeof(int), s), "hipMemsetAsync(poa reference arithmetic)")) ||
+            (rc = e->check(hipMemsetAsync(A.best, 0, 16 * sizeof(int), s), "hipMemsetAsync(poa best)"))) return rc;
+        e->timing_begin(s);
+        const bool single = e->opt_poa_dataflow != 0;       // (0: the second run after an abandoned single launch)
+        const int nl = launch_poa_ref8(B, single, s);
+        if (nl < 0) { e->set_error("poa_ref8: %zu bytes of LDS refused", poa_ref8_lds_bytes(B.maxp, B.Wq)); return TSTA_ERR_INTERNAL; }
+        hipLaunchKernelGGL(poa_best_kernel, dim3(1), dim3(256), 0, s, A);
+        e->n_launches = nl + 1;
+        e->poa_status = single ? B.status : nullptr;
+        e->poa_blocked_w = B.W;
+        return e->check(hipGetLastError(), "poa_fill (reference arithmetic) launch");
     }
 
     // K4d (poa_dataflow.hip): one launch, solver + emitter waves — 2 columns per lane, sequences without a literal 'N'
@@ -1138,6 +1193,12 @@ template <class F, class D> static int poa_with_reference_arithmetic(tsta_engine
     if (rc2 == TSTA_WARN_REFERENCE_UNDEFINED) return rc2;     // (the path could not run: the same result and warning again)
     memcpy(e->warn, keep, sizeof(keep));
     return rc2 < 0 ? rc2 : rc;
+}
+
+extern "C" int tsta_poa_reference_exact(const tsta_params* p, int32_t ref_block, char* why, size_t why_bytes)
+{
+    if (!p || ref_block < 16 || ref_block % 16 != 0) return TSTA_ERR_INVALID_ARG;
+    return tsta::poa_scoring_is_plain_dp(p, ref_block, why, why_bytes) ? 1 : 0;
 }
 
 extern "C" int tsta_poa_fill(tsta_engine* eng, const tsta_params* p, const tsta_dag_csr* dag, const uint8_t* seq,

@@ -1013,6 +1013,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             hipEventRecord(e->ev_fork, s) == hipSuccess && hipStreamWaitEvent(e->side[0], e->ev_fork, 0) == hipSuccess) { ss = e->side[0]; single_on_side = true; }
     }
     bool quad = false;
+    e->last_trace_form = persistent_couples ? 5 : persistent ? 1 : 0;      // tsta_engine_stat("last_trace_form"); refined below
     std::vector<int> diag_tab;
     if constexpr (TRACE && R <= 2) {
         quad = persistent && !persistent_couples && e->opt_trace_lds != 0 && ((single_bands + 3) / 4 <= e->n_cu || e->opt_trace_lds == 2);
@@ -1056,10 +1057,12 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
                 const bool acgt = e->opt_psa_perm != 0 && p->M >= -128 && p->M <= 127 && p->X >= -128 && p->X <= 127 && pure_acgt(jobs[0]);
                 if (acgt) hipLaunchKernelGGL((psa_trace_split_kernel<2, true>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
                 else      hipLaunchKernelGGL((psa_trace_split_kernel<2, false>), dim3((unsigned)n_wg), dim3(kSplitThreads), 0, s, A);
+                e->last_trace_form = acgt ? 4 : 3;
             }
             ++launches;
         } else if (quad) {
             // one pair: bands linked through LDS inside a workgroup of four
+            e->last_trace_form = 2;
             A.d = 0; A.g_lo = 0; A.g_hi = (int)single_bands;
             hipLaunchKernelGGL((psa_trace_quad_kernel<R>), dim3((unsigned)((single_bands + 3) / 4)), dim3(256), 0, s, A);
             ++launches;
