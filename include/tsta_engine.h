@@ -71,6 +71,9 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
  *   "psa_ffree"        1 (default) | 0: never use the frame with both gap extensions free (scorings with X >= -2|E|)
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
+ *   "psa_overlap"      1 (default) | 0: the host-pointer score forms (tsta_psa_score_batch[_multi]) cut a batch worth several full rounds
+ *                      of the chip into sub-batches of whole rounds and upload sub-batch j + 1 on a second stream while j computes
+ *                      (only the first sub-batch's upload is exposed); 0 = one upload, then the kernels
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_packed"     1 (default) | 0: tsta_psa_align_batch never couples two pairs per wave (packed 16-bit trace fill)
  *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream
@@ -162,7 +165,8 @@ int tsta_psa_score_batch_dev(tsta_engine* eng, const tsta_params* p, int64_t n_p
 int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
 /* Counters of an engine: "single_launch_reruns"; "last_trace_form" = how the last tsta_psa_align[_batch] group was filled (0 one
  * launch per tile diagonal, 1 single launch with tiles through memory, 2 LDS-linked quads, 3 / 4 solver bands + emitter tiles
- * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form).  TSTA_ERR_INVALID_ARG for an unknown key. */
+ * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form); "last_sub_batches" = how many sub-batches the last
+ * host-pointer score call was cut into (option "psa_overlap").  TSTA_ERR_INVALID_ARG for an unknown key. */
 int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);
 
 /* 2-bit packed input for pure-ACGT batches: a quarter of the host memory, PCIe traffic and input

@@ -464,3 +464,34 @@ def test_unequal_couples_garbage_stays_in_range(eng):
         assert res == eng.psa_align_batch(sub, prm)
     finally:
         eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("trace_rows", 0); eng.set_option("trace_packed", 1)
+
+
+def test_overlapped_upload_sub_batches(eng):
+    # host-pointer form, batch worth >= 2 full rounds of the chip: cut into sub-batches whose uploads overlap the previous one's
+    # kernels (psa_api.hip).  Ragged pairs, some shared scoring-domain edge; scores = oracle, and the same with the overlap off.
+    n = 2 * 256 * 4 * 2 * 2 + 77
+    pairs = []
+    for i in range(n):
+        l = 40 + (i * 37) % 300
+        a = util.random_dna(70000 + i, l)
+        pairs.append((a, util.mutate(a, 90000 + i, 0.1)) if i % 3 else (a, util.random_dna(80000 + i, max(1, l // 2))))
+    want = util.oracle_maxscore_batch(pairs)
+    got = eng.psa_score_batch(pairs)
+    assert eng.stat("last_sub_batches") >= 2
+    assert np.array_equal(got, want)
+    eng.set_option("psa_overlap", 0)
+    try:
+        got0 = eng.psa_score_batch(pairs)
+        assert eng.stat("last_sub_batches") == 1 and np.array_equal(got0, want)
+    finally:
+        eng.set_option("psa_overlap", 1)
+    # sequences shared between pairs (every record against every record): the sub-batches' byte ranges overlap -> one upload
+    seqs = np.concatenate([p[0] for p in pairs[:100]])
+    lens = np.array([len(p[0]) for p in pairs[:100]], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    ii, jj = np.meshgrid(np.arange(100), np.arange(100), indexing="ij")
+    ii = np.tile(ii.ravel(), 1); jj = jj.ravel()
+    got2 = eng.psa_score_batch_arrays(seqs, offs[ii], lens[ii], offs[jj], lens[jj])
+    assert eng.stat("last_sub_batches") == 1
+    sel = [0, 57, 4242, 9999]
+    assert [int(got2[k]) for k in sel] == [util.oracle_maxscore(pairs[ii[k]][0], pairs[jj[k]][0]) for k in sel]

@@ -329,6 +329,18 @@ class Engine:
         self._check(rc, "tsta_psa_score_batch")
         return out
 
+    def psa_score_batch_arrays(self, seqs, off1, len1, off2, len2, params=None):
+        """tsta_psa_score_batch on arrays already in the batch ABI's layout (host numpy arrays: uint8 bytes, int64 offsets, int32
+        lengths) -> int32 scores.  What bench.py's end-to-end leg times: host-resident shard in, scores on the host out."""
+        params = params or Params()
+        n = len(off1)
+        out = np.zeros(n, dtype=np.int32)
+        if n == 0:
+            return out
+        rc = lib().tsta_psa_score_batch(self._h, C.byref(params), n, _ptr(seqs), len(seqs), _ptr(off1), _ptr(len1), _ptr(off2), _ptr(len2), _ptr(out))
+        self._check(rc, "tsta_psa_score_batch")
+        return out
+
     def psa_score_batch_2bit(self, pairs, params=None):
         """Like psa_score_batch for pure-ACGT pairs, handing the engine 2-bit packed sequences (4 bases per byte)."""
         params = params or Params()

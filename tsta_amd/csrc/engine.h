@@ -21,12 +21,14 @@ struct Engine {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams: independent launch sequences of one call overlap
     hipEvent_t  ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool        timing_valid = false;
+    bool        timing_hold = false;    // timing_begin keeps the start already recorded (a call made of several enqueued parts)
+    hipEvent_t  ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // "sub-batch j is on the device" (overlapped upload, psa_api.hip)
     int         n_launches = 0;
     char        err[512] = {0};
     char        warn[512] = {0};   // text behind the last TSTA_WARN_* status
 
     // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
-    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1;
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1, opt_psa_overlap = 1;
     unsigned* psa_status = nullptr;   // device word the last tsta_psa_score_batch_dev's single-launch band pipeline (K1b) reports into, or null
     bool      no_single_launch = false;   // set around such a second run
     int       single_launch_reruns = 0;   // calls that were run again through the launch pipeline after an abandoned single launch
@@ -36,6 +38,7 @@ struct Engine {
     unsigned* poa_status = nullptr;   // device word the last POA fill's waits report into (dataflow form), or null
     int       last_trace_form = 0;    // how the last trace fill ran: 0 launch per tile diagonal, 1 single launch (tiles through memory), 2 LDS-linked quads,
                                       // 3 / 4 solver bands + emitter tiles (generic / pure-ACGT table), 5 coupled pairs in dataflow form
+    int       last_sub_batches = 1;   // sub-batches the last host-pointer score call was cut into (overlapped upload)
     int align_calls = 0;   // tsta_psa_align_batch calls so far (its workspace cap grows with them)
 
     DevBuf counter;      // ticket counters / flags (zeroed per launch)

@@ -105,7 +105,7 @@ int psa_reference_warning(Engine* e, const tsta_params* p)
     return psa_reference_exact(p, e->warn, sizeof(e->warn)) ? TSTA_OK : TSTA_WARN_REFERENCE_UNDEFINED;
 }
 
-void Engine::timing_begin(hipStream_t s) { timing_stream = s; n_launches = 0; (void)hipEventRecord(ev0, s); }
+void Engine::timing_begin(hipStream_t s) { timing_stream = s; n_launches = 0; if (!timing_hold) (void)hipEventRecord(ev0, s); }
 void Engine::timing_end(hipStream_t s) { (void)hipEventRecord(ev1, s); timing_valid = true; }
 
 }  // namespace tsta
@@ -247,6 +247,7 @@ void tsta_engine_destroy(tsta_engine* eng)
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (int g = 0; g < 3; ++g) { if (e->side[g]) (void)hipStreamDestroy(e->side[g]); if (e->ev_join[g]) (void)hipEventDestroy(e->ev_join[g]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (hipEvent_t ev : e->ev_up) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_tab) (void)hipEventDestroy(e->ev_tab);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -285,6 +286,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_bands") && (v == -1 || v == 0 || v == 8 || v == 16)) { e->opt_psa_bands = (int)v; return TSTA_OK; }
     if (!strcmp(key, "psa_ffree") && (v == 0 || v == 1)) { e->opt_psa_ffree = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_overlap") && (v == 0 || v == 1)) { e->opt_psa_overlap = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
     if (!strcmp(key, "trace_lds") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_lds = v; return TSTA_OK; }
@@ -303,6 +305,7 @@ int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
     const Engine* e = reinterpret_cast<const Engine*>(eng);
     if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
     if (!strcmp(key, "last_trace_form")) { *value = e->last_trace_form; return TSTA_OK; }
+    if (!strcmp(key, "last_sub_batches")) { *value = e->last_sub_batches; return TSTA_OK; }
     return TSTA_ERR_INVALID_ARG;
 }
 

@@ -384,6 +384,16 @@ template <class F> static int psa_score_rerun_if_abandoned(Engine* e, F again)
     return rc;
 }
 
+// the copy stream and the events of the overlapped upload (created on first use)
+static int psa_overlap_streams(Engine* e)
+{
+    if (!e->side[0] && hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking) != hipSuccess) { e->side[0] = nullptr; (void)hipGetLastError(); return TSTA_ERR_HIP; }
+    if (!e->ev_fork && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { e->ev_fork = nullptr; (void)hipGetLastError(); return TSTA_ERR_HIP; }
+    for (hipEvent_t& ev : e->ev_up)
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return TSTA_ERR_HIP; }
+    return TSTA_OK;
+}
+
 // tsta_psa_score_batch proper.  out (host) may be NULL when d_scores is given: the scores then stay on the device, in a
 // buffer of at least max(n_pairs, dev_count) int32 (tsta_psa_score_batch_multi gathers them with RCCL from there), and
 // the stream is synchronised either way.
@@ -432,6 +442,7 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
             return TSTA_OK;
         }
     }
+    e->last_sub_batches = 1;
     std::vector<int64_t> h_off(2 * nb);
     std::vector<int32_t> h_len(2 * nb);
     for (size_t k = 0; k < nb; ++k) { h_off[k] = off1[k]; h_off[nb + k] = off2[k]; h_len[k] = len1[k]; h_len[nb + k] = len2[k]; }
@@ -445,6 +456,57 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
     int32_t* d_len1 = reinterpret_cast<int32_t*>(d_off2 + nb);
     int32_t* d_len2 = d_len1 + nb;
     hipStream_t s = e->stream;
+
+    // ---- upload / compute overlap (">= 2 streams per device"; what the reference's readseq, psa.c:179-217, does before
+    // its fill starts).  A batch worth several full rounds of the chip is cut into sub-batches of whole rounds — contiguous ranges of
+    // pairs; one round = one couple per resident wave of the packed kernel —: sub-batch j + 1 travels on the copy stream while the
+    // kernels of sub-batch j run on the compute stream, so only the FIRST sub-batch's upload is exposed (8 192 pairs of 50 kbp:
+    // 0.41 of 0.82 GB).  Fewer, fuller launches beat more overlap: a sub-batch below one round would leave wave slots empty.
+    {
+        const int64_t round_pairs = (int64_t)e->n_cu * 4 * 2 * 2;                       // 256 CUs x 4 SIMDs x 2 waves x 2 pairs per wave
+        const int64_t n_sub = e->opt_psa_overlap ? std::min<int64_t>(n_pairs / round_pairs, 8) : 1;
+        struct Sub { int64_t lo, hi, b0, b1; };
+        std::vector<Sub> sub;
+        int64_t span = 0;
+        for (int64_t j = 0; j < n_sub && n_sub >= 2; ++j) {
+            Sub u; u.lo = n_pairs * j / n_sub; u.hi = n_pairs * (j + 1) / n_sub; u.b0 = seqs_bytes; u.b1 = 0;
+            for (int64_t k = u.lo; k < u.hi; ++k) {
+                u.b0 = std::min(u.b0, std::min(off1[k], off2[k]));
+                u.b1 = std::max(u.b1, std::max(off1[k] + len1[k], off2[k] + len2[k]));
+            }
+            if (u.b1 < u.b0) { u.b0 = 0; u.b1 = 0; }
+            span += u.b1 - u.b0;
+            sub.push_back(u);
+        }
+        // (sequences shared between pairs — TSTA_psa_batch -A — make the byte ranges overlap: then one upload is cheaper)
+        if (!sub.empty() && span <= seqs_bytes + seqs_bytes / 4 && psa_overlap_streams(e) == TSTA_OK) {
+            hipStream_t cs = e->side[0];
+            if ((rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
+                (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")) ||
+                (rc = e->check(hipEventRecord(e->ev_fork, s), "hipEventRecord(fork)")) ||
+                (rc = e->check(hipStreamWaitEvent(cs, e->ev_fork, 0), "hipStreamWaitEvent(fork)")))      // (the copy stream must not run ahead of
+                return rc;                                                                                 //  an earlier call still reading in_seqs)
+            uint8_t* d_seqs = reinterpret_cast<uint8_t*>(e->in_seqs.p);
+            e->last_sub_batches = (int)sub.size();
+            e->timing_hold = false;
+            for (size_t j = 0; j < sub.size() && rc == TSTA_OK; ++j) {
+                const Sub& u = sub[j];
+                // pageable memory: the runtime stages it chunk by chunk and the call returns when the last chunk is on its way,
+                // i.e. the host thread is here while the kernels of sub-batch j - 1 run
+                if (u.b1 > u.b0) rc = e->check(hipMemcpyAsync(d_seqs + u.b0, seqs + u.b0, (size_t)(u.b1 - u.b0), hipMemcpyHostToDevice, cs), "H2D seqs (sub-batch)");
+                if (rc == TSTA_OK) rc = e->check(hipEventRecord(e->ev_up[j], cs), "hipEventRecord(upload)");
+                if (rc == TSTA_OK) rc = e->check(hipStreamWaitEvent(s, e->ev_up[j], 0), "hipStreamWaitEvent(upload)");
+                if (rc == TSTA_OK) rc = psa_score_batch_dev_impl(e, p, u.hi - u.lo, d_seqs, d_off1 + u.lo, d_len1 + u.lo, d_off2 + u.lo, d_len2 + u.lo,
+                                                                 reinterpret_cast<int32_t*>(e->out_scores.p) + u.lo, max_len, s);
+                e->timing_hold = true;                           // tsta_last_kernel_ms: from the first sub-batch's first kernel to the last one's end
+            }
+            e->timing_hold = false;
+            if (rc != TSTA_OK) { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); return rc; }
+            // (sub-batches of whole rounds never take the small-batch band pipeline: no single launch to run again)
+            if (out && (rc = e->check(hipMemcpyAsync(out, e->out_scores.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H scores"))) return rc;
+            return e->check(hipStreamSynchronize(s), "psa_score_batch sync");
+        }
+    }
     if ((rc = e->check(hipMemcpyAsync(e->in_seqs.p, seqs, (size_t)seqs_bytes, hipMemcpyHostToDevice, s), "H2D seqs")) ||
         (rc = e->check(hipMemcpyAsync(d_off1, h_off.data(), nb * 16, hipMemcpyHostToDevice, s), "H2D offsets")) ||
         (rc = e->check(hipMemcpyAsync(d_len1, h_len.data(), nb * 8, hipMemcpyHostToDevice, s), "H2D lengths")))
