@@ -71,9 +71,9 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
  *   "psa_ffree"        1 (default) | 0: never use the frame with both gap extensions free (scorings with X >= -2|E|)
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
- *   "psa_overlap"      1 (default) | 0: the host-pointer score forms (tsta_psa_score_batch[_multi]) cut a batch worth several full rounds
- *                      of the chip into sub-batches of whole rounds and upload sub-batch j + 1 on a second stream while j computes
- *                      (only the first sub-batch's upload is exposed); 0 = one upload, then the kernels
+ *   "psa_overlap"      1 (default) | 0: the host-pointer score forms (tsta_psa_score_batch[_multi]) cut a batch of at least two balanced
+ *                      launches (4 couples per SIMD each: 8 192 pairs on 256 CUs) into such sub-batches and upload sub-batch j + 1 on a
+ *                      second stream while j computes (only the first sub-batch's upload is exposed); 0 = one upload, then the kernels
  *   "psa_rows"         0 auto | 4 / 8 / 16 rows per lane of the int32 score kernel
  *   "trace_packed"     1 (default) | 0: tsta_psa_align_batch never couples two pairs per wave (packed 16-bit trace fill)
  *   "trace_streams"    0 auto (default: up to 4 overlapping launch sequences in tsta_psa_align_batch) | 1 one stream

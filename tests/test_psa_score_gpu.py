@@ -467,12 +467,12 @@ def test_unequal_couples_garbage_stays_in_range(eng):
 
 
 def test_overlapped_upload_sub_batches(eng):
-    # host-pointer form, batch worth >= 2 full rounds of the chip: cut into sub-batches whose uploads overlap the previous one's
+    # host-pointer form, batch worth >= 2 balanced launches (4 couples per SIMD each): cut into sub-batches whose uploads overlap the previous one's
     # kernels (psa_api.hip).  Ragged pairs, some shared scoring-domain edge; scores = oracle, and the same with the overlap off.
-    n = 2 * 256 * 4 * 2 * 2 + 77
+    n = 2 * 256 * 4 * 4 * 2 + 77
     pairs = []
     for i in range(n):
-        l = 40 + (i * 37) % 300
+        l = 30 + (i * 37) % 150
         a = util.random_dna(70000 + i, l)
         pairs.append((a, util.mutate(a, 90000 + i, 0.1)) if i % 3 else (a, util.random_dna(80000 + i, max(1, l // 2))))
     want = util.oracle_maxscore_batch(pairs)

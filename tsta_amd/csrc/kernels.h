@@ -65,6 +65,7 @@ struct PsaPackedArgs {
     const uint8_t* acgt;            // per pair: 1 iff both sequences consist of the bytes A, C, G, T only (may be null)
     int32_t  elide;                 // 1: blocks that provably cannot raise the maximum run without the running max
     int32_t  ffree;                 // 1: pure-ACGT couples run those blocks in the frame with both gap extensions free (X >= -2|E|)
+    unsigned long long* wave_log;   // diagnostics only (TSTA_PSA_CLOCK=2): per couple {memrealtime begin, end, HW_ID | XCC_ID << 32, slot}
 };
 
 // K1b (psa_trace_packed.hip: psa_score_bands_kernel): band pipeline over the couples of a small batch

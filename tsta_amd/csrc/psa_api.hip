@@ -304,8 +304,12 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
         pa.b.rows = a.rows + need32 / sizeof(int2);
         pa.b.counter = a.counter + 1;
         pa.b.clock_out = nullptr;
-        if (want_clock && e->reserve(e->scratch2, 256, "diag") == TSTA_OK)
+        pa.wave_log = nullptr;
+        static const bool want_log = want_clock && atoi(getenv("TSTA_PSA_CLOCK")) == 2;
+        if (want_clock && e->reserve(e->scratch2, 256 + (want_log ? (size_t)couples * 32 : 0), "diag") == TSTA_OK) {
             pa.b.clock_out = reinterpret_cast<unsigned long long*>(e->scratch2.p);
+            if (want_log) { pa.wave_log = pa.b.clock_out + 32; (void)hipMemsetAsync(pa.wave_log, 0, (size_t)couples * 32, s); }
+        }
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         pa.pe = ae | (ae << 16); pa.po = ao | (ao << 16); pa.pm = am | (am << 16); pa.pmx = amx | (amx << 16);
         // the frame of the elided blocks spreads the rows of a band by |E| each: needs that much more of the 16-bit window
@@ -330,6 +334,24 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
             hipStreamSynchronize(s) == hipSuccess && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, R, (long long)blocks);
+        if (couples && Rp && atoi(getenv("TSTA_PSA_CLOCK")) == 2 && e->scratch2.p) {
+            // per couple: when and where it ran -> TSTA_PSA_CLOCK_FILE (text: ticket begin_us end_us xcc se cu simd wave slot)
+            std::vector<unsigned long long> w((size_t)couples * 4);
+            if (e->copy_sync(w.data(), reinterpret_cast<unsigned long long*>(e->scratch2.p) + 32, w.size() * 8, hipMemcpyDeviceToHost, "D2H wave log") == TSTA_OK) {
+                const char* fn = getenv("TSTA_PSA_CLOCK_FILE");
+                if (FILE* f = fopen(fn ? fn : "psa_wave_log.txt", "w")) {
+                    unsigned long long t0 = ~0ull;
+                    for (int64_t c = 0; c < couples; ++c) if (w[4 * c + 1]) t0 = std::min(t0, w[4 * c]);
+                    for (int64_t c = 0; c < couples; ++c) {
+                        if (!w[4 * c + 1]) continue;
+                        const unsigned hw = (unsigned)w[4 * c + 2], xcc = (unsigned)(w[4 * c + 2] >> 32) & 15u;
+                        fprintf(f, "%lld %.1f %.1f %u %u %u %u %u %llu\n", (long long)c, (double)(w[4 * c] - t0) / 100.0, (double)(w[4 * c + 1] - t0) / 100.0,
+                                xcc, (hw >> 13) & 7u, (hw >> 8) & 15u, (hw >> 4) & 3u, hw & 15u, w[4 * c + 3]);
+                    }
+                    fclose(f);
+                }
+            }
+        }
         if (couples && e->scratch2.p && e->copy_sync(h, e->scratch2.p, sizeof(h), hipMemcpyDeviceToHost, "D2H clock") == TSTA_OK && h[3] > h[1])
             fprintf(stderr, "[tsta] psa_score_packed wave0: %.1f ms, shader clock %.0f MHz (R=%d, %lld blocks, %d blocks/CU by API)\n",
                     (double)(h[3] - h[1]) / 1e5, (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0, Rp, (long long)pblocks,
@@ -458,12 +480,16 @@ int psa_score_batch_host(Engine* e, const tsta_params* p, int64_t n_pairs, const
     hipStream_t s = e->stream;
 
     // ---- upload / compute overlap (">= 2 streams per device"; what the reference's readseq, psa.c:179-217, does before
-    // its fill starts).  A batch worth several full rounds of the chip is cut into sub-batches of whole rounds — contiguous ranges of
-    // pairs; one round = one couple per resident wave of the packed kernel —: sub-batch j + 1 travels on the copy stream while the
-    // kernels of sub-batch j run on the compute stream, so only the FIRST sub-batch's upload is exposed (8 192 pairs of 50 kbp:
-    // 0.41 of 0.82 GB).  Fewer, fuller launches beat more overlap: a sub-batch below one round would leave wave slots empty.
+    // its fill starts).  A large batch is cut into sub-batches — contiguous ranges of pairs —: sub-batch j + 1 travels on the copy
+    // stream while the kernels of sub-batch j run on the compute stream, so only the FIRST sub-batch's upload is exposed.
+    // The size of a sub-batch is not free (measured, tests/tools/wave_log.py + e2e_timing.py, 50 kbp pairs): a SIMD serves its two
+    // resident waves oldest-first — the older wave takes a couple in 716 ms (a lone wave: 637), the younger one in 2 189 ms while
+    // the older does three — so a launch is balanced when every SIMD gets 4 couples (3 + 1; 8 192 pairs on 256 CUs: 2 189 ms =
+    // 4 x 547), and a launch of 2 couples per SIMD takes 1 214 ms instead of 1 094: cutting the 8 192-pair shard in two costs
+    // 10 %, twenty times the 11 ms of upload it would hide.  Hence: sub-batches of 4 couples per SIMD, and a batch below two of
+    // them goes up in one piece (exposed upload of an 8 192 x 50 kbp shard: 0.5 %).
     {
-        const int64_t round_pairs = (int64_t)e->n_cu * 4 * 2 * 2;                       // 256 CUs x 4 SIMDs x 2 waves x 2 pairs per wave
+        const int64_t round_pairs = (int64_t)e->n_cu * 4 * 4 * 2;                       // 256 CUs x 4 SIMDs x 4 couples x 2 pairs
         const int64_t n_sub = e->opt_psa_overlap ? std::min<int64_t>(n_pairs / round_pairs, 8) : 1;
         struct Sub { int64_t lo, hi, b0, b1; };
         std::vector<Sub> sub;

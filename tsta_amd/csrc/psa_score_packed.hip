@@ -225,12 +225,19 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         const int nA = swa ? l2a : l1a, mA = swa ? l1a : l2a;
         const int nB = swb ? l2b : l1b, mB = swb ? l1b : l2b;
         int ra, rb;
+        const unsigned long long t_begin = P.wave_log ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
         const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
         if (perm && P.ffree) pscore_couple<R, true, true>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         else if (perm)       pscore_couple<R, true, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         else                 pscore_couple<R, false, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
         if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
+        if (P.wave_log && lane == 0) {                            // where and when this couple ran (diagnostics)
+            unsigned long long* w = P.wave_log + 4 * (size_t)ticket;
+            w[0] = t_begin; w[1] = __builtin_amdgcn_s_memrealtime();
+            w[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
+            w[3] = (unsigned long long)slot;
+        }
         wave_mem_sync();
     }
     if (stamp) { A.clock_out[2] = __builtin_amdgcn_s_memtime(); A.clock_out[3] = __builtin_amdgcn_s_memrealtime(); }
