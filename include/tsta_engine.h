@@ -71,6 +71,12 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      the block cannot raise the pair's maximum (exact either way; see psa_score_packed.hip)
  *   "psa_ffree"        1 (default) | 0: never use the frame with both gap extensions free (scorings with X >= -2|E|)
  *   "psa_perm"         1 (default) | 0: never use the byte-permute mismatch lookup for pure-ACGT pairs
+ *   "psa_f16max"       1 (default) | 0: the packed score kernel keeps its biased 16-bit scores inside the bit patterns of positive normal
+ *                      binary16 numbers where a band's plausible spread allows, and takes the three-way maximum of a cell as ONE
+ *                      v_pk_maximum3_f16 in every 64-step block whose operands provably stay there (exact: for those patterns the
+ *                      IEEE order is the integer order); a couple whose scores leave the 16-bit window is scored by the int32 kernel.
+ *                      1 = where the host's estimate of a band's spread fits that range | 0 = round-3 behaviour (two v_pk_max_u16) |
+ *                      2 = whatever the estimate says | 3 / 4 (tests): as 2 without the fast step / with every couple to the int32 kernel
  *   "psa_overlap"      1 (default) | 0: the host-pointer score forms (tsta_psa_score_batch[_multi]) cut a batch of at least two balanced
  *                      launches (4 couples per SIMD each: 8 192 pairs on 256 CUs) into such sub-batches and upload sub-batch j + 1 on a
  *                      second stream while j computes (only the first sub-batch's upload is exposed); 0 = one upload, then the kernels

@@ -495,3 +495,55 @@ def test_overlapped_upload_sub_batches(eng):
     assert eng.stat("last_sub_batches") == 1
     sel = [0, 57, 4242, 9999]
     assert [int(got2[k]) for k in sel] == [util.oracle_maxscore(pairs[ii[k]][0], pairs[jj[k]][0]) for k in sel]
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=2, X=-4, E=-4, O=-2), dict(M=3, X=-9, E=-7, O=-5),
+                                     dict(M=6, X=-20, E=-3, O=-12)])
+def test_f16_order_maximum_every_mode(eng, scoring):
+    # the packed kernel with its scores kept as positive-normal binary16 bit patterns (option "psa_f16max"): steady blocks whose
+    # operands provably stay in range take max3 as one v_pk_maximum3_f16 (2: always that kernel; 1: where the host's estimate allows),
+    # the same kernel without the fast step (3), every couple handed to the int32 kernel through the redo flags (4), and the
+    # round-3 kernel (0).  Content that spreads a band's scores:
+    # identical sequences (rows far below the diagonal lie 64 R |E| under the band's top row), unrelated ones, long indels, couples of
+    # unequal size, lengths around the band / block boundaries.
+    pairs = []
+    for i, n in enumerate([64, 65, 300, 1023, 1024, 1025, 2047, 2048, 2049, 2500, 4096, 5000, 5000, 6200]):
+        a = util.random_dna(310_000 + i, n)
+        pairs.append((a, a.copy()))                                                        # identical
+        pairs.append((a, util.mutate(a, 320_000 + i, 0.1)))                                # related
+        pairs.append((a, util.random_dna(330_000 + i, max(1, n - (i % 5) * 7))))           # unrelated, slightly ragged
+        pairs.append((a, np.concatenate([a[:n // 3], a[n // 3 + min(n // 4, 400):]])))     # one long gap
+        pairs.append((np.full(n, ord("A"), np.uint8), np.full(max(1, n - 3 * (i % 4)), ord("A"), np.uint8)))   # homopolymer: flat H'
+    want = util.oracle_maxscore_batch(pairs, **scoring)
+    prm = tsta_amd.Params(**scoring)
+    try:
+        for packed in (32, 16, 8):
+            eng.set_option("psa_packed", packed)
+            for mode in (2, 1, 3, 4, 0):
+                eng.set_option("psa_f16max", mode)
+                for elide in (1, 0):
+                    eng.set_option("psa_elide", elide)
+                    got = eng.psa_score_batch(pairs, prm)
+                    assert np.array_equal(got, want), (scoring, packed, mode, elide, np.nonzero(got != want)[0][:8].tolist())
+    finally:
+        eng.set_option("psa_packed", -1); eng.set_option("psa_f16max", 1); eng.set_option("psa_elide", 1)
+
+
+def test_f16_order_maximum_worst_case_spread_falls_back(eng):
+    # scores that DO leave the binary16-pattern range inside a band (|E| = 7: 2 048 rows below the diagonal of identical sequences lie
+    # 14 336 under the band's top row) and ones that leave the 16-bit window around 0x4000 altogether (|E| = 12 at 32 rows per lane):
+    # forced into the F3 instantiation (mode 2), results must still be the oracle's
+    pairs = []
+    for i, n in enumerate([2100, 4200, 5000, 9000]):
+        a = util.random_dna(340_000 + i, n)
+        pairs += [(a, a.copy()), (a, util.mutate(a, 350_000 + i, 0.03)), (a, util.random_dna(360_000 + i, n))]
+    try:
+        eng.set_option("psa_packed", 32)
+        for scoring in (dict(M=2, X=-5, E=-7, O=-4), dict(M=1, X=-3, E=-12, O=0), dict(M=5, X=-5, E=-1, O=-30)):
+            want = util.oracle_maxscore_batch(pairs, **scoring)
+            for mode in (2, 0):
+                eng.set_option("psa_f16max", mode)
+                got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+                assert np.array_equal(got, want), (scoring, mode, np.nonzero(got != want)[0][:8].tolist())
+    finally:
+        eng.set_option("psa_packed", -1); eng.set_option("psa_f16max", 1)

@@ -84,6 +84,47 @@ KERNEL(k_alt, R8("v_sub_u32 %2, %2, %14\nv_pk_max_u16 %3, %3, %14\nv_sub_u32 %4,
 KERNEL(k_max32, R8("v_max_u32 %2, %2, %14\nv_max_u32 %3, %3, %14\nv_max_u32 %4, %4, %14\nv_max_u32 %5, %5, %14\n"), 32)
 KERNEL(k_alt32, R8("v_sub_u32 %2, %2, %14\nv_max_u32 %3, %3, %14\nv_sub_u32 %4, %4, %14\nv_max_u32 %5, %5, %14\n"), 32)
 
+// round 4: the three-input packed maximum of gfx950 (v_pk_maximum3_f16) on BIT PATTERNS: for patterns in [0x0400, 0x7bff]
+// (positive normal halves: no NaN / inf / denormal / zero) the IEEE order is the unsigned integer order, so it is an exact
+// u16 max3 there.  Does it issue like v_pk_max_u16?
+KERNEL(k_pkmax3, R8("v_pk_maximum3_f16 %2, %2, %14, %15\nv_pk_maximum3_f16 %3, %3, %14, %15\nv_pk_maximum3_f16 %4, %4, %14, %15\nv_pk_maximum3_f16 %5, %5, %14, %15\n"), 32)
+KERNEL(k_pkmaxf, R8("v_pk_max_f16 %2, %2, %14\nv_pk_max_f16 %3, %3, %14\nv_pk_max_f16 %4, %4, %14\nv_pk_max_f16 %5, %5, %14\n"), 32)
+// the elided row with it: 7 instead of 8 instructions
+#define ROW3(FB, HL, SEL)                                \
+    "v_sub_u32 %11, " FB ", %14\n"                       \
+    "v_perm_b32 %10, %17, %16, " SEL "\n"                \
+    "v_sub_u32 %12, " HL ", %10\n"                       \
+    "v_pk_maximum3_f16 " HL ", %12, %0, %11\n"           \
+    "v_sub_u32 %13, " HL ", %15\n"                       \
+    "v_pk_max_u16 " FB ", %11, %13\n"                    \
+    "v_pk_max_u16 %0, %0, %13\n"
+KERNEL(k_rows3, ROW3("%2", "%6", "%18") ROW3("%3", "%7", "%19") ROW3("%4", "%8", "%20") ROW3("%5", "%9", "%21"), 28)
+// ... and the free-free frame's row (no f-sub): 6
+#define ROW3FF(FB, HL, SEL)                              \
+    "v_perm_b32 %10, %17, %16, " SEL "\n"                \
+    "v_add_u32 %12, " HL ", %10\n"                       \
+    "v_pk_maximum3_f16 " HL ", %12, %0, " FB "\n"        \
+    "v_sub_u32 %13, " HL ", %15\n"                       \
+    "v_pk_max_u16 " FB ", " FB ", %13\n"                 \
+    "v_pk_max_u16 %0, %0, %13\n"
+KERNEL(k_rows3ff, ROW3FF("%2", "%6", "%18") ROW3FF("%3", "%7", "%19") ROW3FF("%4", "%8", "%20") ROW3FF("%5", "%9", "%21"), 24)
+
+// exactness of the bit-pattern trick: every pair of halves (a, b) on a grid over [0x0400, 0x7bff] and a third operand
+__global__ void k_max3_exact(unsigned* bad, unsigned lo, unsigned hi)
+{
+    const unsigned a = lo + blockIdx.x;                        // one block per value of a
+    unsigned n = 0;
+    for (unsigned b = lo + threadIdx.x; b <= hi; b += blockDim.x) {
+        const unsigned c = lo + ((a * 2654435761u + b * 40503u) % (hi - lo + 1));
+        const unsigned pa = a | (b << 16), pb = b | (c << 16), pc = c | (a << 16);
+        unsigned r;
+        asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(pa), "v"(pb), "v"(pc));
+        const unsigned m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+        if ((r & 0xffffu) != m || (r >> 16) != m) ++n;
+    }
+    if (n) atomicAdd(bad, n);
+}
+
 typedef void (*kern_t)(unsigned long long*, int, int);
 struct Test { const char* name; kern_t k; int instr; };
 
@@ -93,7 +134,20 @@ int main()
                     {"4 rows, slow ops only (20)", k_rows_slow, 20}, {"4 rows, fast ops only (12)", k_rows_fast, 12},
                     {"4 rows, clustered (32)", k_clustered, 32}, {"v_perm_b32", k_perm, 32}, {"v_pk_max_u16", k_pkmax, 32},
                     {"v_sub_u32", k_sub, 32}, {"alternating sub / pk_max", k_alt, 32}, {"v_max_u32", k_max32, 32},
-                    {"alternating sub / max_u32", k_alt32, 32}};
+                    {"alternating sub / max_u32", k_alt32, 32}, {"v_pk_maximum3_f16", k_pkmax3, 32}, {"v_pk_max_f16", k_pkmaxf, 32},
+                    {"4 rows with pk_maximum3 (28)", k_rows3, 28}, {"4 rows, free-free, pk_maximum3 (24)", k_rows3ff, 24}};
+    {   // exactness first
+        unsigned* bad; hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+        const unsigned lo = 0x0400, hi = 0x7bff;
+        hipLaunchKernelGGL(k_max3_exact, dim3(hi - lo + 1), dim3(256), 0, 0, bad, lo, hi);
+        unsigned h = 0; hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("v_pk_maximum3_f16 as u16 max3 on patterns [0x%04x, 0x%04x]: %u mismatches over %u x %u triples\n", lo, hi, h, hi - lo + 1, hi - lo + 1);
+        hipMemset(bad, 0, 4);
+        hipLaunchKernelGGL(k_max3_exact, dim3(0x7fff - 0x0001 + 1), dim3(256), 0, 0, bad, 0x0001u, 0x7fffu);
+        hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("   (outside that range, patterns [0x0001, 0x7fff]: %u mismatches — denormals / NaN patterns)\n", h);
+        hipFree(bad);
+    }
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int ncu = prop.multiProcessorCount;
     unsigned long long* d; hipMalloc(&d, sizeof(unsigned long long) * ((1 << 20) + 8));

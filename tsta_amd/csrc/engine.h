@@ -28,7 +28,7 @@ struct Engine {
     char        warn[512] = {0};   // text behind the last TSTA_WARN_* status
 
     // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
-    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1, opt_psa_overlap = 1;
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1, opt_psa_overlap = 1, opt_psa_f16max = 1;
     unsigned* psa_status = nullptr;   // device word the last tsta_psa_score_batch_dev's single-launch band pipeline (K1b) reports into, or null
     bool      no_single_launch = false;   // set around such a second run
     int       single_launch_reruns = 0;   // calls that were run again through the launch pipeline after an abandoned single launch

@@ -287,6 +287,7 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "psa_ffree") && (v == 0 || v == 1)) { e->opt_psa_ffree = v; return TSTA_OK; }
     if (!strcmp(key, "psa_perm") && (v == 0 || v == 1)) { e->opt_psa_perm = v; return TSTA_OK; }
     if (!strcmp(key, "psa_overlap") && (v == 0 || v == 1)) { e->opt_psa_overlap = v; return TSTA_OK; }
+    if (!strcmp(key, "psa_f16max") && v >= 0 && v <= 4) { e->opt_psa_f16max = v; return TSTA_OK; }
     if (!strcmp(key, "poa_cols") && (v == 0 || v == 2 || v == 4)) { e->opt_poa_cols = v; return TSTA_OK; }
     if (!strcmp(key, "align_ws_gb") && v >= 0 && v <= 4096) { e->opt_align_ws_gb = v; return TSTA_OK; }
     if (!strcmp(key, "trace_lds") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_lds = v; return TSTA_OK; }

@@ -20,6 +20,8 @@ struct PsaBatchArgs {
     unsigned long long* clock_out;   // diagnostics only (TSTA_PSA_CLOCK=1): {memtime, memrealtime} x {begin, end} of wave 0
     int64_t        packed_couples;  // couples of positions (2c, 2c+1), c < packed_couples, are tried by the packed kernel first
     const uint32_t* order;          // position -> pair index (pairs ordered by geometry so neighbours are similar); NULL = identity
+    uint8_t*       redo;            // per pair (zeroed before the launches, may be null): 1 = the packed kernel gave the pair up (its scores
+                                    // left the 16-bit window, psa_score_packed.hip: F3) and the int32 kernel scores it after all
 };
 
 __host__ __device__ inline int64_t psa_pair_at(const uint32_t* order, int64_t pos) { return order ? (int64_t)order[pos] : pos; }
@@ -65,6 +67,9 @@ struct PsaPackedArgs {
     const uint8_t* acgt;            // per pair: 1 iff both sequences consist of the bytes A, C, G, T only (may be null)
     int32_t  elide;                 // 1: blocks that provably cannot raise the maximum run without the running max
     int32_t  ffree;                 // 1: pure-ACGT couples run those blocks in the frame with both gap extensions free (X >= -2|E|)
+    int32_t  f3;                    // 0: bias 0x8000, u16 maxima (window guaranteed by the host's bound) | 1: bias 0x4000, steady blocks whose
+                                    // operands provably stay positive normal binary16 patterns take max3 as one v_pk_maximum3_f16 |
+                                    // 2, 3 (tests): as 1 but never the fast step / every couple given up to the int32 kernel
     unsigned long long* wave_log;   // diagnostics only (TSTA_PSA_CLOCK=2): per couple {memrealtime begin, end, HW_ID | XCC_ID << 32, slot}
 };
 

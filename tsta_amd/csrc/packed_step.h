@@ -40,7 +40,9 @@ struct PLane {
 // diagonal term then needs no "+M":  D' = H'(i-1,j-1) - (match ? 0 : M-X);  the vertical gap is unchanged
 // (E' = Ebar'(i-1,j) - |E|, same column) and the horizontal gap pays the shift:  F' = Fbar'(i,j-1) - (|E|+M).
 // That removes one add per cell; the price is one add + one max per STEP to feed the running max in the H frame.
-template <int R, bool PRED, bool PARTIAL, bool PERM>
+// F3: the three-way maximum as ONE v_pk_maximum3_f16 (packed_ops.h: pkmax3f) — the caller guarantees that every operand of the
+// block lies in the range where that is an exact u16 max3.
+template <int R, bool PRED, bool PARTIAL, bool PERM, bool F3 = false>
 __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, const int n, const int nA, const int nB,
                                       const int nvA, const int nvB,
                                       const unsigned pe, const unsigned po, const unsigned pm, const unsigned pmx,
@@ -60,7 +62,7 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
         const unsigned f = s.fb[k] - pf;                 // F' = Fbar'(left) - (|E|+M)
         const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);   // 0 or M-X
         const unsigned dg = d - tt;                      // D' = H'diag - (match ? 0 : M-X)
-        h = pkmax(pkmax(dg, e), f);
+        h = F3 ? pkmax3f(dg, e, f) : pkmax(pkmax(dg, e), f);
         const unsigned g = h - po;                       // H' + O
         const unsigned eb = pkmax(e, g);
         const unsigned fbn = pkmax(f, g);
@@ -106,7 +108,7 @@ __device__ __forceinline__ void pstep(PLane<R>& s, const int t, const int lane, 
 //     H+(i,c) = H'(i,c) + |E|*(i - top) + (|E|+M)*(c - c_ref)
 // in which BOTH gap extensions cost nothing; the diagonal then ADDS 2|E|+M (match) or 2|E|+X (mismatch, >= 0 by the
 // condition), which the column's byte table delivers directly: 7 VALU per cell pair.
-template <int R, bool PERM, bool FF = false>
+template <int R, bool PERM, bool FF = false, bool F3 = false>
 __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, const unsigned pmx, const unsigned pf2)
 {
     static_assert(!FF || PERM, "the free-free frame needs the byte-table lookup");
@@ -120,7 +122,7 @@ __device__ __forceinline__ void pstep_elided(PLane<R>& s, const unsigned po, con
         const unsigned f = FF ? s.fb[k] : s.fb[k] - pf2; // F* = Fbar*(left) - (2|E|+M);  F+ = Fbar+(left)
         const unsigned tt = mismatch_term<PERM>(s.cch, s.cch2, s.bch[k], pmx);
         const unsigned dg = FF ? d + tt : d - tt;        // FF: the table holds 2|E|+M / 2|E|+X
-        h = pkmax(pkmax(dg, eu), f);                     // E* = Ebar*(up): no subtraction
+        h = F3 ? pkmax3f(dg, eu, f) : pkmax(pkmax(dg, eu), f);   // E* = Ebar*(up): no subtraction
         const unsigned g = h - po;
         d = s.hl[k];
         s.hl[k] = h;
@@ -159,8 +161,8 @@ __device__ __forceinline__ void elided_frame(PLane<R>& s, const int ln, const EF
     { const int v = sign * (lane_part + F.ae * R); const unsigned pv = pack2(v, v); s.hbot = pkadd(s.hbot, pv); s.ebot = pkadd(s.ebot, pv); }
 }
 
-template <int R>
-__device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx(s.mx, acc); }
+template <int R, int BIAS = kBias>
+__device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx<BIAS>(s.mx, acc); }
 
 
 
@@ -170,10 +172,10 @@ __device__ __forceinline__ void fold_max(PLane<R>& s, PairAcc& acc) { fold_mx(s.
 // beyond a pair's end enter at the bias level; (2) once no lane of the wave is on a real column of that pair any more
 // (t0 - 63 >= its n) its half of the lane state is flattened to the bias at the start of every block, so it can drift
 // by at most 64 columns' worth of score.
-template <int R>
+template <int R, int BIAS = kBias>
 __device__ __forceinline__ void flatten_half(PLane<R>& s, const bool low)
 {
-    const unsigned keep = low ? 0xffff0000u : 0x0000ffffu, fill = low ? (unsigned)kBias : ((unsigned)kBias << 16);
+    const unsigned keep = low ? 0xffff0000u : 0x0000ffffu, fill = low ? (unsigned)BIAS : ((unsigned)BIAS << 16);
 #pragma unroll
     for (int k = 0; k < R; ++k) { s.hl[k] = (s.hl[k] & keep) | fill; s.fb[k] = (s.fb[k] & keep) | fill; }
     // (hbot / ebot are left alone: lane 63's still hold the pair's LAST real column on their way into the bottom row;
@@ -181,20 +183,20 @@ __device__ __forceinline__ void flatten_half(PLane<R>& s, const bool low)
     s.hd = (s.hd & keep) | fill;
     s.th = (s.th & keep) | fill; s.te = (s.te & keep) | fill;
 }
-template <int R>
+template <int R, int BIAS = kBias>
 __device__ __forceinline__ void bound_garbage_columns(PLane<R>& s, const int t0, const int ln, const int nA, const int nB)
 {
     const int c = t0 + ln;                              // column of this lane's top-row entry
-    if (c >= nA) { s.th = (s.th & 0xffff0000u) | (unsigned)kBias; s.te = (s.te & 0xffff0000u) | (unsigned)kBias; }
-    if (c >= nB) { s.th = (s.th & 0x0000ffffu) | ((unsigned)kBias << 16); s.te = (s.te & 0x0000ffffu) | ((unsigned)kBias << 16); }
-    if (t0 - 63 >= nA) flatten_half<R>(s, true);
-    if (t0 - 63 >= nB) flatten_half<R>(s, false);
+    if (c >= nA) { s.th = (s.th & 0xffff0000u) | (unsigned)BIAS; s.te = (s.te & 0xffff0000u) | (unsigned)BIAS; }
+    if (c >= nB) { s.th = (s.th & 0x0000ffffu) | ((unsigned)BIAS << 16); s.te = (s.te & 0x0000ffffu) | ((unsigned)BIAS << 16); }
+    if (t0 - 63 >= nA) flatten_half<R, BIAS>(s, true);
+    if (t0 - 63 >= nB) flatten_half<R, BIAS>(s, false);
 }
 
 // Can the 64-step block starting at t0 raise either pair's maximum?  (see pstep_elided)  Entering H' values: the lanes'
 // previous-column rows, the diagonal entries and the 64 top-row entries; rows beyond the end of a pair hold garbage
 // that no real cell ever reads and do not count.  `in_star`: the lane state is currently in the H* frame.
-template <int R, bool PARTIAL>
+template <int R, bool PARTIAL, int BIAS = kBias>
 __device__ __forceinline__ bool block_cannot_raise_max(const PLane<R>& s, const PairAcc& acc, const bool in_star, const int ln,
                                                        const EFrame F, const int nvA, const int nvB, const bool rowsA, const bool rowsB,
                                                        const int t0, const int M)
@@ -210,9 +212,27 @@ __device__ __forceinline__ bool block_cannot_raise_max(const PLane<R>& s, const 
         if (PARTIAL) hv &= ((k < nvA) ? 0xffffu : 0u) | ((k < nvB) ? 0xffff0000u : 0u);
         v = pkmax(v, hv);
     }
-    const int ubA = wave_max((int)(v & 0xffffu)) - kBias + acc.baseA + (t0 + 64) * M;
-    const int ubB = wave_max((int)(v >> 16)) - kBias + acc.baseB + (t0 + 64) * M;
+    const int ubA = wave_max((int)(v & 0xffffu)) - BIAS + acc.baseA + (t0 + 64) * M;
+    const int ubB = wave_max((int)(v >> 16)) - BIAS + acc.baseB + (t0 + 64) * M;
     return ubA <= max(wave_max(acc.mxA), -100) && ubB <= max(wave_max(acc.mxB), -100);
+}
+
+// Range of everything a 64-step block starts from, per half, over the whole wave: the lanes' rows hl[], the diagonal entry and the
+// 64 top-row entries (Fbar, Ebar and the bottom-row pair lie within |O| below their H).  lo = packed minima, hi = packed maxima.
+// What the block computes from them moves by at most `per step` bounds the caller knows, so one look per block decides whether the
+// block may run with pkmax3f (operands inside [kF16Lo, kF16Hi]), must run with the two-instruction u16 maximum, or has left the
+// 16-bit window altogether.
+template <int R>
+__device__ __forceinline__ void block_range(const PLane<R>& s, unsigned& lo, unsigned& hi)
+{
+    lo = pkmin(s.hd, s.th); hi = pkmax(s.hd, s.th);
+#pragma unroll
+    for (int k = 0; k < R; ++k) { lo = pkmin(lo, s.hl[k]); hi = pkmax(hi, s.hl[k]); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = pkmin(lo, (unsigned)__shfl_xor((int)lo, off, 64));
+        hi = pkmax(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+    }
 }
 
 }  // namespace tsta

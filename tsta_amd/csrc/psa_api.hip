@@ -50,6 +50,22 @@ static int psa_packed_rows_per_lane(const tsta_params& p, int64_t couples, int m
     return best;
 }
 
+// Should the packed kernel run its F3 instantiation (kernels.h: PsaPackedArgs::f3)?  Exactness never depends on the answer — the
+// kernel checks every block's range itself and hands a couple that leaves the 16-bit window to the int32 kernel —, only speed does:
+// where the scores of a band plausibly spread beyond what the binary16-pattern range (30 719 wide) holds, blocks would fall back to
+// the two-instruction maximum or couples to the int32 kernel.  Estimate: (64 R rows + 256 columns) at the long-range rate M + |E| per
+// step, twice the gap open, plus the block margins the kernel uses.  option "psa_f16max": 0 never, 1 auto, 2 always (whatever the
+// estimate says), 3 / 4 (tests) always, and without the fast step / with every couple handed to the int32 kernel.
+static int psa_f16max_mode(const tsta_params& p, int R, int opt)
+{
+    if (opt == 0) return 0;
+    if (opt >= 2) return opt - 1;
+    const int64_t ae = -(int64_t)p.E, ao = -(int64_t)p.O, M = p.M, mx = (int64_t)p.M - p.X;
+    const int64_t spread = (64LL * R + 256) * (M + ae) + 2 * ao;
+    const int64_t margins = 66 * (mx + ao + 2 * ae + M) + 66 * (2 * ae + M) + 130 * M;
+    return spread + margins < 15000 ? 1 : 0;
+}
+
 // K1b (band pipeline over the couples of a batch, psa_trace_packed.hip: psa_score_bands_kernel) pays when K1p could
 // not give every SIMD two waves: fewer couples than 2x the SIMDs, sequences of at least two bands.  Returns rows per
 // lane (16 or 8) or 0; `rows_bytes` = the boundary-row workspace it needs (every band of every pair keeps its own row).
@@ -215,14 +231,22 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
     a.n_pairs = n_pairs; a.M = p->M; a.X = p->X; a.E = p->E; a.O = p->O;
     a.packed_couples = couples;
     a.order = couples ? tsta::psa_order_by_geometry(e, d_len1, d_len2, n_pairs, s) : nullptr;
+    a.redo = nullptr;
     static const bool want_clock = getenv("TSTA_PSA_CLOCK") != nullptr;      // diagnostics: in-kernel shader clock
     a.clock_out = want_clock ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->counter.p) + 64) : nullptr;
 
     if ((rc = e->check(hipMemsetAsync(a.counter, 0, 2 * sizeof(unsigned int), s), "hipMemsetAsync")) != TSTA_OK) return rc;
     const uint8_t* acgt = nullptr;
-    if (couples && e->opt_psa_perm != 0 && p->M - p->X <= 255 &&
-        e->reserve(e->pair_flags, (size_t)n_pairs, "hipMalloc(alphabet flags)") == TSTA_OK)
+    if (couples && (rc = e->reserve(e->pair_flags, 2 * (size_t)n_pairs, "hipMalloc(pair flags)")) != TSTA_OK) return rc;   // [alphabet flags][redo flags]
+    if (couples && e->opt_psa_perm != 0 && p->M - p->X <= 255)
         acgt = reinterpret_cast<const uint8_t*>(e->pair_flags.p);
+    // F3: scores around 0x4000 so that a steady block's three-way maximum can be one v_pk_maximum3_f16 (psa_score_packed.hip); a couple
+    // whose scores leave the 16-bit window on the way is handed to the int32 kernel through these flags
+    const int f3 = (couples && Rp) ? tsta::psa_f16max_mode(*p, Rp, e->opt_psa_f16max) : 0;
+    if (f3) {
+        a.redo = reinterpret_cast<uint8_t*>(e->pair_flags.p) + n_pairs;
+        if ((rc = e->check(hipMemsetAsync(a.redo, 0, (size_t)n_pairs, s), "hipMemsetAsync(redo flags)")) != TSTA_OK) return rc;
+    }
     e->timing_begin(s);
     int launches = 0;
     if (couples && Rb) {
@@ -315,6 +339,7 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
         // the frame of the elided blocks spreads the rows of a band by |E| each: needs that much more of the 16-bit window
         pa.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rp) + (int64_t)ae * (32 * (Rp + 1) + 192) < 28000;
         pa.acgt = acgt;
+        pa.f3 = f3;
         pa.ffree = acgt && e->opt_psa_ffree != 0 && tsta::psa_ffree_ok(p->M, p->X, p->E, p->O, Rp);
         if (acgt) {
             hipLaunchKernelGGL(tsta::psa_alphabet_flags_kernel, dim3((unsigned)std::min<int64_t>(n_pairs, 65536)), dim3(256), 0, s,

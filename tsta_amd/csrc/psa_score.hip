@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void psa_score_batch_kernel(PsaBatchArgs A)
         if (lane == 0) ticket = atomicAdd(A.counter, 1u);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if ((int64_t)ticket >= A.n_pairs) break;               // every wave reaches this exit
-        if ((int64_t)(ticket >> 1) < A.packed_couples && psa_couple_is_packed(A.len1, A.len2, A.order, ticket >> 1))
-            continue;                                           // scored by the packed-int16 kernel
         const int64_t pi = psa_pair_at(A.order, ticket);
+        if ((int64_t)(ticket >> 1) < A.packed_couples && psa_couple_is_packed(A.len1, A.len2, A.order, ticket >> 1) &&
+            !(A.redo != nullptr && A.redo[pi] != 0))
+            continue;                                           // scored by the packed-int16 kernel (unless it gave the pair up)
         const int l1 = A.len1[pi], l2 = A.len2[pi];
         const uint8_t* s1 = A.seqs + A.off1[pi];
         const uint8_t* s2 = A.seqs + A.off2[pi];

@@ -25,15 +25,23 @@ namespace tsta {
 
 // The two pairs of a couple may differ in size: the wave sweeps max(nA,nB) columns and max(mA,mB) rows; cells
 // outside the smaller pair compute garbage that only feeds other such cells and is masked out of its running max.
-template <int R, bool PARTIAL, bool PERM, bool FF>
-__device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int nA, const int nB,
+// F3 (round 4): the kernel keeps its scores around the bias 0x4000 instead of 0x8000, so that they are bit patterns of positive
+// normal binary16 numbers, and a steady 64-step block whose operands provably stay inside [0x0400, 0x7bff] takes the three-way
+// maximum of every cell as ONE v_pk_maximum3_f16 (7 instead of 8 instructions per cell pair).  The proof is a look at the block's
+// entering values (block_range) plus what 64 steps can move them by (`mdn` down, `mup` up): a block that fails it runs the
+// two-instruction u16 maximum as before (any value of the 16-bit window is fine for that), and a block that would leave the 16-bit
+// window altogether makes the band return false — the couple is then scored by the int32 kernel (PsaBatchArgs::redo).
+// F3 == false is the round-3 kernel unchanged (bias 0x8000, window guaranteed by the host's bound).
+template <int R, bool PARTIAL, bool PERM, bool FF, bool F3>
+__device__ __forceinline__ bool pband(const uint8_t* __restrict__ aA, const uint8_t* __restrict__ aB, const int nA, const int nB,
                                       const uint8_t* __restrict__ bA, const uint8_t* __restrict__ bB, const int mA, const int mB,
                                       const bool store_bottom,
                                       const int band_row0, int2* __restrict__ rowA, int2* __restrict__ rowB,
                                       PairAcc& acc, const int lane, const int M, const int E, const int O,
                                       const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
-                                      const bool elide_ok)
+                                      const bool elide_ok, const int f3_mode)
 {
+    constexpr int kBias = F3 ? 0x4000 : tsta::kBias;      // (shadows the namespace constant inside this band)
     const unsigned pe = in_vgpr(pe_s), po = in_vgpr(po_s), pm = in_vgpr(pm_s), pmx = in_vgpr(pmx_s);
     const unsigned pf = pe + pm;                   // |E| + M: the horizontal gap pays the column shift of the H' frame
     const unsigned pf2 = pf + pe;                  // 2|E| + M: the same in the frame of the elided blocks
@@ -91,7 +99,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         int lag = 64;            // columns the lane has moved since the H* frame's reference column was set
         if (t0 > 0 && t0 < n) {
             // re-anchor both pairs to the band's top row at column t0
-            fold_max<R>(s, acc);
+            fold_max<R, kBias>(s, acc);
             // (a pair whose columns are exhausted keeps its last anchor: its lanes hold garbage from here on)
             const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)pt.x);
             const int nbA = (t0 < nA) ? (int)(p0 & 0xffffu) - kBias + bw.x : acc.baseA;
@@ -105,7 +113,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
             for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
             s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
         } else if (t0 >= n) {
-            fold_max<R>(s, acc);                   // last (drain) block keeps the previous anchor
+            fold_max<R, kBias>(s, acc);                   // last (drain) block keeps the previous anchor
         }
         // running-max anchor of this block: column index t0-63 in the H frame
         acc.ancA = acc.baseA + (t0 - 62) * M;
@@ -127,7 +135,7 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         const bool steady = t0 >= 64 && t0 + 63 < nmin;
         bool elide = false;
         if (steady && elide_ok) {
-            elide = block_cannot_raise_max<R, PARTIAL>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M);
+            elide = block_cannot_raise_max<R, PARTIAL, kBias>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M);
         }
         if (elide != in_star) {                        // frame change only where the kind of block changes
             if (elide) elided_frame<R>(s, ln, F, +1, 0);
@@ -137,17 +145,39 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         }
         if (PERM) { s.ach = (FF && elide) ? cm4 - tabA : tabA; s.ach2 = (FF && elide) ? cm4 - tabB : tabB; }
         else      s.ach = tabA;
+        if (elide) { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+        bool fast = false;
+        if (F3) {
+            // where does the block start from, and can 64 steps take it out of range?  Down: a step lowers a value by at most a mismatch
+            // plus a gap open, intermediates by a gap extension more; up: only the free-free frame's diagonal adds (2|E|+M per step)
+            unsigned lo, hi;
+            block_range<R>(s, lo, hi);
+            const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
+            const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
+            const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;           // (+ the running max's column offset, <= 127 M)
+            if (lo_min < mdn || hi_max > 0xffff - mup || f3_mode == 3) return false;   // leaves the 16-bit window: the int32 kernel takes the couple
+            fast = f3_mode != 2 && lo_min >= (int)kF16Lo + mdn && hi_max <= (int)kF16Hi - mup;
+        }
         if (elide) {
-            { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+            if (F3 && fast) {
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF>(s, po, pmx, pf2);
+                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF, true>(s, po, pmx, pf2);
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF>(s, po, pmx, pf2);
+            }
             // the 64 captured bottom-row entries (column t0-64+lane): row 64R below the top, 63-lane columns behind t0-1
             { const int v = -eframe_bottom_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if (steady) {
+            if (F3 && fast) {
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+                for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM, true>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep<R, false, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            }
         } else {
-            if (nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);   // beyond the shorter pair's end: keep its half in range
+            if (nA != nB) bound_garbage_columns<R, kBias>(s, t0, ln, nA, nB);   // beyond the shorter pair's end: keep its half in range
 #pragma unroll 1
             for (int q = 0; q < 64; ++q) pstep<R, true, PARTIAL, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
@@ -155,16 +185,18 @@ __device__ __forceinline__ void pband(const uint8_t* __restrict__ aA, const uint
         if (store_bottom && cs >= 0 && cs < n) rowP[cs] = make_uint2(s.sh, s.se);      // this block's captures, in this block's frame
         if (store_bottom && t0 >= 64 && ln == 0) rowS[(t0 - 64) >> 6] = make_int2(acc.baseA, acc.baseB);
     }
-    fold_max<R>(s, acc);
+    fold_max<R, kBias>(s, acc);
+    return true;
 }
 
-template <int R, bool PERM, bool FF>
-__device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
+template <int R, bool PERM, bool FF, bool F3>
+__device__ __forceinline__ bool pscore_couple(const uint8_t* aA, const uint8_t* bA, const uint8_t* aB, const uint8_t* bB,
                                               int nA, int mA, int nB, int mB, int2* rowA, int2* rowB, int lane,
                                               int M, int E, int O,
-                                              unsigned pe, unsigned po, unsigned pm, unsigned pmx, bool elide_ok,
+                                              unsigned pe, unsigned po, unsigned pm, unsigned pmx, bool elide_ok, int f3_mode,
                                               int& outA, int& outB)
 {
+    constexpr int kBias = F3 ? 0x4000 : tsta::kBias;      // as in pband
     const int n = max(nA, nB), mmax = max(mA, mB), mmin = min(mA, mB);
     {   // blockmatrix_init, psa.c:221-226: H(0,c+1) = O + (c+1)E, Ebar = H + O, in the packed row format of pband: H' = H - (c+1)M
         // relative to the block's first column
@@ -178,28 +210,30 @@ __device__ __forceinline__ void pscore_couple(const uint8_t* aA, const uint8_t* 
     wave_mem_sync();
     PairAcc acc; acc.baseA = 0; acc.baseB = 0; acc.ancA = 0; acc.ancB = 0; acc.mxA = kNegInfP; acc.mxB = kNegInfP;
     constexpr int BAND = 64 * R;
-    for (int r0 = 0; r0 < mmax; r0 += BAND) {
+    bool ok = true;
+    for (int r0 = 0; r0 < mmax && ok; r0 += BAND) {
         const bool last = r0 + BAND >= mmax;
         const int rem = mmax - r0;
         // The LAST band need not be as tall as the others: the boundary-row format does not depend on R, so the rows that are
         // left are swept with the smallest band that covers them (50 000 rows = 24 bands of 2 048 + 848: a 1 024-row band
         // instead of a 2 048-row one, 0.35 % instead of 2.4 % of padded rows).  Its window is a subset of the tall band's.
         if (R >= 16 && rem <= 64 * 8) {
-            if (r0 + 64 * 8 <= mmin) pband<8, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-            else                     pband<8, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+            if (r0 + 64 * 8 <= mmin) ok = pband<8, false, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
+            else                     ok = pband<8, true, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
         } else if (R >= 32 && rem <= 64 * 16) {
-            if (r0 + 64 * 16 <= mmin) pband<16, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-            else                      pband<16, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+            if (r0 + 64 * 16 <= mmin) ok = pband<16, false, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
+            else                      ok = pband<16, true, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, false, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
         }
-        else if (r0 + BAND <= mmin) pband<R, false, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
-        else                        pband<R, true, PERM, FF>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok);
+        else if (r0 + BAND <= mmin) ok = pband<R, false, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
+        else                        ok = pband<R, true, PERM, FF, F3>(aA, aB, nA, nB, bA, bB, mA, mB, !last, r0, rowA, rowB, acc, lane, M, E, O, pe, po, pm, pmx, elide_ok, f3_mode);
         if (!last) wave_mem_sync();
     }
     outA = wave_max(acc.mxA);
     outB = wave_max(acc.mxB);
+    return ok;
 }
 
-template <int R, int WAVES>
+template <int R, int WAVES, bool F3>
 __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedArgs P)
 {
     const PsaBatchArgs& A = P.b;
@@ -225,13 +259,17 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
         const int nA = swa ? l2a : l1a, mA = swa ? l1a : l2a;
         const int nB = swb ? l2b : l1b, mB = swb ? l1b : l2b;
         int ra, rb;
+        bool ok;
         const unsigned long long t_begin = P.wave_log ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
-        const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
-        if (perm && P.ffree) pscore_couple<R, true, true>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
-        else if (perm)       pscore_couple<R, true, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
-        else                 pscore_couple<R, false, false>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, ra, rb);
-        if (lane == 0) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
+        const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb] & 1)) != 0;
+        if (perm && P.ffree) ok = pscore_couple<R, true, true, F3>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3, ra, rb);
+        else if (perm)       ok = pscore_couple<R, true, false, F3>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3, ra, rb);
+        else                 ok = pscore_couple<R, false, false, F3>(aA, bA, aB, bB, nA, mA, nB, mB, rowA, rowB, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3, ra, rb);
+        if (lane == 0) {
+            if (ok) { A.out[pa] = max(ra, -100); A.out[pb] = max(rb, -100); }    // ms floor, psa.c:110,590
+            else    { A.redo[pa] = 1; A.redo[pb] = 1; }                         // left the 16-bit window: psa_score_batch_kernel takes both pairs
+        }
         if (P.wave_log && lane == 0) {                            // where and when this couple ran (diagnostics)
             unsigned long long* w = P.wave_log + 4 * (size_t)ticket;
             w[0] = t_begin; w[1] = __builtin_amdgcn_s_memrealtime();
@@ -243,19 +281,28 @@ __global__ __launch_bounds__(256, WAVES) void psa_score_packed_kernel(PsaPackedA
     if (stamp) { A.clock_out[2] = __builtin_amdgcn_s_memtime(); A.clock_out[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// f3 (PsaPackedArgs::f3 != 0): the instantiations whose scores sit around 0x4000 and whose steady blocks may use v_pk_maximum3_f16
 void launch_psa_score_packed(int R, const PsaPackedArgs& args, int blocks, hipStream_t stream)
 {
-    if (R == 8)       hipLaunchKernelGGL((psa_score_packed_kernel<8, 4>), dim3(blocks), dim3(256), 0, stream, args);
-    else if (R == 32) hipLaunchKernelGGL((psa_score_packed_kernel<32, 2>), dim3(blocks), dim3(256), 0, stream, args);
-    else              hipLaunchKernelGGL((psa_score_packed_kernel<16, 3>), dim3(blocks), dim3(256), 0, stream, args);
+    const bool f3 = args.f3 != 0;
+    if (R == 8) {
+        if (f3) hipLaunchKernelGGL((psa_score_packed_kernel<8, 4, true>), dim3(blocks), dim3(256), 0, stream, args);
+        else    hipLaunchKernelGGL((psa_score_packed_kernel<8, 4, false>), dim3(blocks), dim3(256), 0, stream, args);
+    } else if (R == 32) {
+        if (f3) hipLaunchKernelGGL((psa_score_packed_kernel<32, 2, true>), dim3(blocks), dim3(256), 0, stream, args);
+        else    hipLaunchKernelGGL((psa_score_packed_kernel<32, 2, false>), dim3(blocks), dim3(256), 0, stream, args);
+    } else {
+        if (f3) hipLaunchKernelGGL((psa_score_packed_kernel<16, 3, true>), dim3(blocks), dim3(256), 0, stream, args);
+        else    hipLaunchKernelGGL((psa_score_packed_kernel<16, 3, false>), dim3(blocks), dim3(256), 0, stream, args);
+    }
 }
 
 int psa_packed_blocks_per_cu(int R)
 {
     int nb = 0;
-    hipError_t e = (R == 8)  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<8, 4>, 256, 0)
-                 : (R == 32) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<32, 2>, 256, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<16, 3>, 256, 0);
+    hipError_t e = (R == 8)  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<8, 4, true>, 256, 0)
+                 : (R == 32) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<32, 2, true>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_packed_kernel<16, 3, true>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb > 8 ? 8 : nb;
 }
