@@ -525,8 +525,15 @@ def test_f16_order_maximum_every_mode(eng, scoring):
                     eng.set_option("psa_elide", elide)
                     got = eng.psa_score_batch(pairs, prm)
                     assert np.array_equal(got, want), (scoring, packed, mode, elide, np.nonzero(got != want)[0][:8].tolist())
+        eng.set_option("psa_packed", -1)
+        for bands in (16, 8):                                   # the band pipeline (K1b) shares the step and the range check
+            eng.set_option("psa_bands", bands)
+            for mode in (2, 1, 3, 4, 0):
+                eng.set_option("psa_f16max", mode)
+                got = eng.psa_score_batch(pairs, prm)
+                assert np.array_equal(got, want), (scoring, "bands", bands, mode, np.nonzero(got != want)[0][:8].tolist())
     finally:
-        eng.set_option("psa_packed", -1); eng.set_option("psa_f16max", 1); eng.set_option("psa_elide", 1)
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("psa_f16max", 1); eng.set_option("psa_elide", 1)
 
 
 def test_f16_order_maximum_worst_case_spread_falls_back(eng):
@@ -543,7 +550,9 @@ def test_f16_order_maximum_worst_case_spread_falls_back(eng):
             want = util.oracle_maxscore_batch(pairs, **scoring)
             for mode in (2, 0):
                 eng.set_option("psa_f16max", mode)
-                got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
-                assert np.array_equal(got, want), (scoring, mode, np.nonzero(got != want)[0][:8].tolist())
+                for packed, bands in ((32, -1), (-1, 16)):
+                    eng.set_option("psa_packed", packed); eng.set_option("psa_bands", bands)
+                    got = eng.psa_score_batch(pairs, tsta_amd.Params(**scoring))
+                    assert np.array_equal(got, want), (scoring, mode, packed, bands, np.nonzero(got != want)[0][:8].tolist())
     finally:
-        eng.set_option("psa_packed", -1); eng.set_option("psa_f16max", 1)
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("psa_f16max", 1)

@@ -80,6 +80,7 @@ struct PsaBandsArgs {
     const uint8_t* acgt;            // per pair: 1 iff pure ACGT (may be null), as in PsaPackedArgs
     int32_t  elide;                 // as in PsaPackedArgs
     int32_t  ffree;                 // as in PsaPackedArgs
+    int32_t  f3;                    // as in PsaPackedArgs (b.redo must then be set)
     int64_t  rows_per_pair;         // (W_max+1) * row_stride
     int      W_max, T, d;           // bands per pair at max_len, tile length (steps), launch index
     uint32_t pe, po, pm, pmx;       // |E|, |O|, M, M-X replicated in both 16-bit halves

@@ -242,7 +242,7 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
         acgt = reinterpret_cast<const uint8_t*>(e->pair_flags.p);
     // F3: scores around 0x4000 so that a steady block's three-way maximum can be one v_pk_maximum3_f16 (psa_score_packed.hip); a couple
     // whose scores leave the 16-bit window on the way is handed to the int32 kernel through these flags
-    const int f3 = (couples && Rp) ? tsta::psa_f16max_mode(*p, Rp, e->opt_psa_f16max) : 0;
+    const int f3 = couples ? tsta::psa_f16max_mode(*p, Rp ? Rp : Rb, e->opt_psa_f16max) : 0;
     if (f3) {
         a.redo = reinterpret_cast<uint8_t*>(e->pair_flags.p) + n_pairs;
         if ((rc = e->check(hipMemsetAsync(a.redo, 0, (size_t)n_pairs, s), "hipMemsetAsync(redo flags)")) != TSTA_OK) return rc;
@@ -262,6 +262,7 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
         const uint32_t ae = (uint32_t)(-p->E), ao = (uint32_t)(-p->O), am = (uint32_t)p->M, amx = (uint32_t)(p->M - p->X);
         ba.pe = ae | (ae << 16); ba.po = ao | (ao << 16); ba.pm = am | (am << 16); ba.pmx = amx | (amx << 16);
         ba.acgt = acgt;
+        ba.f3 = f3;
         ba.ffree = acgt && e->opt_psa_ffree != 0 && tsta::psa_ffree_ok(p->M, p->X, p->E, p->O, Rb);
         ba.elide = e->opt_psa_elide != 0 && tsta::psa_packed_window(p->M, p->X, p->E, p->O, Rb) + (int64_t)ae * (32 * (Rb + 1) + 192) < 28000;
         if (acgt) {

@@ -160,12 +160,19 @@ struct CoupleView {
 // it depends on ran in OTHER waves of the same launch, so everything it exchanges with them — top row in, bottom row
 // out, the band's lane state in and out — goes through sc1 loads / stores (handoff.h); the kernel around it waits for the
 // two producer tiles before and publishes this band's progress after.
-template <int R, bool TRACE, bool PERM, bool FF = false, bool PERSIST = false>
-__device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
+// F3 (score-only tiles): as in psa_score_packed.hip — scores around the bias 0x4000 (bit patterns of positive normal binary16
+// numbers), a steady block whose operands provably stay in [0x0400, 0x7bff] takes max3 as one v_pk_maximum3_f16; returns false when a
+// block would leave the 16-bit window (the caller flags the couple for the int32 kernel).  The lane state between tiles holds the
+// same biased values: every tile of a launch uses the same instantiation.
+template <int R, bool TRACE, bool PERM, bool FF = false, bool PERSIST = false, bool F3 = false>
+__device__ __forceinline__ bool packed_tile(const CoupleView& V, const int s0, const int s1, const int lane,
                                             const int M, const int E, const int O,
                                             const unsigned pe_s, const unsigned po_s, const unsigned pm_s, const unsigned pmx_s,
-                                            const bool elide_ok)
+                                            const bool elide_ok, const int f3_mode = 0)
 {
+    static_assert(!F3 || !TRACE, "the binary16-order maximum is for score-only tiles");
+    constexpr int kBias = F3 ? 0x4000 : tsta::kBias;      // (shadows the namespace constant inside this tile)
+    bool in_window = true;
     constexpr int SPB = TraceCfg<TRACE ? R : 4>::SPB;
     const int nA = V.nA, mA = V.mA, nB = V.nB, mB = V.mB, w = V.w;
     const int n = max(nA, nB), nmin = min(nA, nB), mmin = min(mA, mB);
@@ -256,7 +263,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         lag = 64;
         if (t0 > 0 && t0 < n) {
             // re-anchor both jobs to the band's top row at column t0 (a job whose columns are exhausted keeps its anchor)
-            fold_mx(s.mx, acc);
+            fold_mx<kBias>(s.mx, acc);
             const int nbA = (t0 < nA) ? __builtin_amdgcn_readfirstlane(ntA.x) - (t0 + 1) * M : acc.baseA;
             const int nbB = (t0 < nB) ? __builtin_amdgcn_readfirstlane(ntB.x) - (t0 + 1) * M : acc.baseB;
             // (in the H* frame the reference column moves along with the block: +64|E| on everything)
@@ -268,7 +275,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             for (int k = 0; k < R; ++k) { s.hl[k] = pksub(s.hl[k], pd); s.fb[k] = pksub(s.fb[k], pd); }
             s.hd = pksub(s.hd, pd); s.hbot = pksub(s.hbot, pd); s.ebot = pksub(s.ebot, pd);
         } else if (t0 >= n) {
-            fold_mx(s.mx, acc);                    // drain block keeps the previous anchor
+            fold_mx<kBias>(s.mx, acc);                    // drain block keeps the previous anchor
         }
         acc.ancA = acc.baseA + (t0 - 62) * M;      // running-max anchor of this block: column t0-63 in the H frame
         acc.ancB = acc.baseB + (t0 - 62) * M;
@@ -296,8 +303,8 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         // blocks that provably cannot raise either maximum run without the running max, in the H* frame (packed_step.h)
         bool elide = false;
         if (steady && elide_ok)
-            elide = partial ? block_cannot_raise_max<R, true>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
-                            : block_cannot_raise_max<R, false>(s, acc, in_star, ln, F, nvA, nvB, true, true, t0, M);
+            elide = partial ? block_cannot_raise_max<R, true, kBias>(s, acc, in_star, ln, F, nvA, nvB, mA > band_row0, mB > band_row0, t0, M)
+                            : block_cannot_raise_max<R, false, kBias>(s, acc, in_star, ln, F, nvA, nvB, true, true, t0, M);
         if (elide != in_star) {                        // frame change only where the kind of block changes
             if (elide) elided_frame<R>(s, ln, F, +1, 0);
             else       elided_frame<R>(s, ln, F, -1, lag);
@@ -306,28 +313,51 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
         }
         if (PERM) { s.ach = (FF && elide) ? cm4 - tabA : tabA; s.ach2 = (FF && elide) ? cm4 - tabB : tabB; }
         else      s.ach = tabA;
+        if (elide) { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
+        bool fast = false;
+        if (F3) {                                      // the block's range against what 64 steps can move it by (psa_score_packed.hip)
+            unsigned lo, hi;
+            block_range<R>(s, lo, hi);
+            const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
+            const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
+            const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;
+            if (lo_min < mdn || hi_max > 0xffff - mup || f3_mode == 3) in_window = false;   // (the tile is finished all the same: its
+            fast = in_window && f3_mode != 2 && lo_min >= (int)kF16Lo + mdn && hi_max <= (int)kF16Hi - mup;   //  dependants must not wait)
+        }
         if (elide) {
-            { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
             if constexpr (TRACE) {
                 ptblock<R, false, false, PERM, true>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf2, K, tqA, tqB);
+            } else if (F3 && fast) {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF, true>(s, po, pmx, pf2);
             } else {
 #pragma unroll 2
                 for (int q = 0; q < 64; ++q) pstep_elided<R, PERM, FF>(s, po, pmx, pf2);
             }
             { const int v = -eframe_bottom_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.sh = pkadd(s.sh, pv); s.se = pkadd(s.se, pv); }
         } else if constexpr (TRACE) {
-            if (!steady && nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);   // beyond the shorter job's end: keep its half in range
+            if (!steady && nA != nB) bound_garbage_columns<R, kBias>(s, t0, ln, nA, nB);   // beyond the shorter job's end: keep its half in range
             if (steady && !partial)      ptblock<R, false, false, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
             else if (steady)             ptblock<R, false, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
             else                         ptblock<R, true, true, PERM, false>(s, t0, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf, K, tqA, tqB);
         } else if (steady && !partial) {
+            if (F3 && fast) {
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+                for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM, true>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep<R, false, false, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            }
         } else if (steady) {
+            if (F3 && fast) {
 #pragma unroll 2
-            for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+                for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM, true>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < 64; ++q) pstep<R, false, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
+            }
         } else {
-            if (nA != nB) bound_garbage_columns<R>(s, t0, ln, nA, nB);
+            if (nA != nB) bound_garbage_columns<R, kBias>(s, t0, ln, nA, nB);
 #pragma unroll 1
             for (int q = 0; q < 64; ++q) pstep<R, true, true, PERM>(s, t0 + q, lane, n, nA, nB, nvA, nvB, pe, po, pm, pmx, pf);
         }
@@ -340,7 +370,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
             else         { botA[cs] = make_int2(hA, eA); botB[cs] = make_int2(hB, eB); }
         }
     }
-    fold_mx(s.mx, acc);
+    fold_mx<kBias>(s.mx, acc);
     auto sv = [&](int idx, int v) { if (PERSIST) store_sc1_int(&st[idx * 64], v); else st[idx * 64] = v; };
 #pragma unroll
     for (int k = 0; k < R; ++k) { sv(2 * k, (int)s.hl[k]); sv(2 * k + 1, (int)s.fb[k]); }
@@ -350,6 +380,7 @@ __device__ __forceinline__ void packed_tile(const CoupleView& V, const int s0, c
     sv(2 * R + 6, acc.baseA); sv(2 * R + 7, acc.baseB);
     sv(2 * R + 8, in_star ? 1 : 0);
     if (PERM) sv(2 * R + 9, (int)s.cch2);
+    return in_window;
 }
 
 // PERSIST = false: one tile of the launch-per-diagonal pipeline (launch d advances every band by one T-step tile).
@@ -448,7 +479,7 @@ __global__ void psa_trace_packed_finish_kernel(const TraceJob* jobs, const Trace
 // PERSIST: the same tiles as ONE launch in dataflow form (see psa_trace_packed_tile_kernel<.., true>): tickets enumerate the
 // tiles d-major, a wave waits for the band's previous tile and the upper band's tile 64 steps further, runs the tile with sc1
 // loads / stores of rows and lane state, publishes.
-template <int R, bool PERSIST>
+template <int R, bool PERSIST, bool F3>
 __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
 {
     constexpr int NS = packed_state_ints(R);
@@ -505,10 +536,12 @@ __global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
         if (w > 0)  wait_progress(prog - 1, min(s1 + 64, S_total), P.status, lane);            // the band above, 64 steps further
     }
     // both pairs pure ACGT (flags from psa_alphabet_flags_kernel): the mismatch term is one byte-permute lookup
-    const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb])) != 0;
-    if (perm && P.ffree) packed_tile<R, false, true, true, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
-    else if (perm)       packed_tile<R, false, true, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
-    else                 packed_tile<R, false, false, false, PERSIST>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0);
+    const bool perm = P.acgt != nullptr && __builtin_amdgcn_readfirstlane((int)(P.acgt[pa] & P.acgt[pb] & 1)) != 0;
+    bool ok;
+    if (perm && P.ffree) ok = packed_tile<R, false, true, true, PERSIST, F3>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3);
+    else if (perm)       ok = packed_tile<R, false, true, false, PERSIST, F3>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3);
+    else                 ok = packed_tile<R, false, false, false, PERSIST, F3>(V, s0, s1, lane, A.M, A.E, A.O, P.pe, P.po, P.pm, P.pmx, P.elide != 0, P.f3);
+    if (F3 && !ok && lane == 0) { A.redo[pa] = 1; A.redo[pb] = 1; }           // left the 16-bit window: psa_score_batch_kernel scores both pairs
     if (!PERSIST) return;
     if (!mute) publish_progress(prog, s1, lane);
     }
@@ -547,19 +580,25 @@ __global__ void psa_score_bands_finish_kernel(PsaBandsArgs P)
 
 void launch_psa_score_bands(int R, const PsaBandsArgs& args, int blocks, hipStream_t stream)
 {
-    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16, false>), dim3(blocks), dim3(256), 0, stream, args);
-    else         hipLaunchKernelGGL((psa_score_bands_kernel<8, false>), dim3(blocks), dim3(256), 0, stream, args);
+    const bool f3 = args.f3 != 0;
+    if (R == 16) { if (f3) hipLaunchKernelGGL((psa_score_bands_kernel<16, false, true>), dim3(blocks), dim3(256), 0, stream, args);
+                   else    hipLaunchKernelGGL((psa_score_bands_kernel<16, false, false>), dim3(blocks), dim3(256), 0, stream, args); }
+    else         { if (f3) hipLaunchKernelGGL((psa_score_bands_kernel<8, false, true>), dim3(blocks), dim3(256), 0, stream, args);
+                   else    hipLaunchKernelGGL((psa_score_bands_kernel<8, false, false>), dim3(blocks), dim3(256), 0, stream, args); }
 }
 
 void launch_psa_score_bands_persistent(int R, const PsaBandsArgs& args, int n_cu, hipStream_t stream)
 {
+    const bool f3 = args.f3 != 0;
     int nb = 0;
-    hipError_t e = (R == 16) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<16, true>, 256, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<8, true>, 256, 0);
+    hipError_t e = (R == 16) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<16, true, true>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<8, true, true>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(((int64_t)args.n_tiles + 3) / 4, (int64_t)n_cu * std::min(nb, 2)));
-    if (R == 16) hipLaunchKernelGGL((psa_score_bands_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
-    else         hipLaunchKernelGGL((psa_score_bands_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    if (R == 16) { if (f3) hipLaunchKernelGGL((psa_score_bands_kernel<16, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
+                   else    hipLaunchKernelGGL((psa_score_bands_kernel<16, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args); }
+    else         { if (f3) hipLaunchKernelGGL((psa_score_bands_kernel<8, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
+                   else    hipLaunchKernelGGL((psa_score_bands_kernel<8, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args); }
 }
 
 void launch_psa_score_bands_finish(int R, const PsaBandsArgs& args, hipStream_t stream)
