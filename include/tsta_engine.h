@@ -172,7 +172,9 @@ int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
 /* Counters of an engine: "single_launch_reruns"; "last_trace_form" = how the last tsta_psa_align[_batch] group was filled (0 one
  * launch per tile diagonal, 1 single launch with tiles through memory, 2 LDS-linked quads, 3 / 4 solver bands + emitter tiles
  * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form); "last_sub_batches" = how many sub-batches the last
- * host-pointer score call was cut into (option "psa_overlap").  TSTA_ERR_INVALID_ARG for an unknown key. */
+ * host-pointer score call was cut into (option "psa_overlap"); "psa_redo_pairs" = pairs of the last score call whose scores left
+ * the packed kernel's 16-bit window and were scored by the int32 kernel instead (option "psa_f16max"; synchronises the device).
+ * TSTA_ERR_INVALID_ARG for an unknown key. */
 int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);
 
 /* 2-bit packed input for pure-ACGT batches: a quarter of the host memory, PCIe traffic and input

@@ -536,6 +536,27 @@ def test_f16_order_maximum_every_mode(eng, scoring):
         eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("psa_f16max", 1); eng.set_option("psa_elide", 1)
 
 
+def test_f16_order_maximum_keeps_ordinary_batches_on_the_packed_kernels(eng):
+    # no couple of ordinary inputs may be handed to the int32 kernel (that would be exact, and three times slower): ragged related /
+    # unrelated pairs through K1p (forced) and through the band pipeline, default scoring
+    pairs = []
+    for i in range(300):
+        n = 500 + (i * 131) % 4000
+        a = util.random_dna(370_000 + i, n)
+        pairs.append((a, util.mutate(a, 380_000 + i, 0.08)) if i % 2 else (a, util.random_dna(390_000 + i, max(1, n - i % 50))))
+    want = util.oracle_maxscore_batch(pairs)
+    try:
+        for packed, bands in ((32, -1), (16, -1), (-1, 16), (-1, 8)):
+            eng.set_option("psa_packed", packed); eng.set_option("psa_bands", bands)
+            assert np.array_equal(eng.psa_score_batch(pairs), want)
+            assert eng.stat("psa_redo_pairs") == 0, (packed, bands)
+        eng.set_option("psa_f16max", 4); eng.set_option("psa_packed", 32); eng.set_option("psa_bands", -1)
+        assert np.array_equal(eng.psa_score_batch(pairs), want)
+        assert eng.stat("psa_redo_pairs") > 0                      # (the counter does see a redo)
+    finally:
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("psa_f16max", 1)
+
+
 def test_f16_order_maximum_worst_case_spread_falls_back(eng):
     # scores that DO leave the binary16-pattern range inside a band (|E| = 7: 2 048 rows below the diagonal of identical sequences lie
     # 14 336 under the band's top row) and ones that leave the 16-bit window around 0x4000 altogether (|E| = 12 at 32 rows per lane):

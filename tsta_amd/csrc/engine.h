@@ -38,6 +38,7 @@ struct Engine {
     unsigned* poa_status = nullptr;   // device word the last POA fill's waits report into (dataflow form), or null
     int       last_trace_form = 0;    // how the last trace fill ran: 0 launch per tile diagonal, 1 single launch (tiles through memory), 2 LDS-linked quads,
                                       // 3 / 4 solver bands + emitter tiles (generic / pure-ACGT table), 5 coupled pairs in dataflow form
+    const uint8_t* last_redo = nullptr; int64_t last_redo_n = 0;   // redo flags of the last score call (psa_score_packed.hip: F3), for tsta_engine_stat
     int       last_sub_batches = 1;   // sub-batches the last host-pointer score call was cut into (overlapped upload)
     int align_calls = 0;   // tsta_psa_align_batch calls so far (its workspace cap grows with them)
 

@@ -187,6 +187,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (const char* v = getenv("TSTA_TRACE_STREAMS")) e->opt_trace_streams = atoi(v);
     if (const char* v = getenv("TSTA_PSA_BANDS")) e->opt_psa_bands = atoi(v);
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
+    if (const char* v = getenv("TSTA_PSA_F16MAX")) e->opt_psa_f16max = std::max(0, std::min(4, atoi(v)));
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
@@ -266,6 +267,7 @@ int tsta_engine_release_workspaces(tsta_engine* eng)
     for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
                             &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
         if (b->p) { e->forget_status_in(*b); (void)hipFree(b->p); }
+        if (b == &e->pair_flags) { e->last_redo = nullptr; e->last_redo_n = 0; }
         b->p = nullptr; b->bytes = 0;
     }
     return TSTA_OK;
@@ -307,6 +309,16 @@ int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
     if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
     if (!strcmp(key, "last_trace_form")) { *value = e->last_trace_form; return TSTA_OK; }
     if (!strcmp(key, "last_sub_batches")) { *value = e->last_sub_batches; return TSTA_OK; }
+    if (!strcmp(key, "psa_redo_pairs")) {               // pairs of the last score call the packed kernels handed to the int32 kernel (synchronises)
+        *value = 0;
+        if (!e->last_redo || e->last_redo_n <= 0 || !e->pair_flags.p) return TSTA_OK;
+        std::vector<uint8_t> h((size_t)e->last_redo_n);
+        Engine* me = const_cast<Engine*>(e);
+        if (me->check(hipSetDevice(e->device), "hipSetDevice") != TSTA_OK || me->check(hipDeviceSynchronize(), "hipDeviceSynchronize") != TSTA_OK ||
+            me->check(hipMemcpy(h.data(), e->last_redo, h.size(), hipMemcpyDeviceToHost), "D2H redo flags") != TSTA_OK) return TSTA_ERR_HIP;
+        for (uint8_t x : h) *value += x != 0;
+        return TSTA_OK;
+    }
     return TSTA_ERR_INVALID_ARG;
 }
 

@@ -55,10 +55,11 @@ __device__ __forceinline__ void wait_progress(const int* word, int need, unsigne
         const int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const GlobalI32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (cur >= need) break;
         const int far = (need - cur) >> 7;                      // 64-step blocks take >= 12 us: 3.4 us of sleep per 128 steps is safe
-        // once any wave has given up, nobody waits any more and the launch drains quickly: looked at before every LONG sleep (a far
-        // wait sleeps up to 108 us per spin: looking only every 256 spins let every later wait of an abandoned launch take ~28 ms to
-        // drain) and every 256 spins when near (~50 ns per spin; looking every 16 cost config #2 35 %)
-        if ((far > 0 || (spins & 255) == 255) &&
+        // once any wave has given up, nobody waits any more and the launch drains quickly.  How often a waiting wave looks at that ONE
+        // word matters: thousands of waves poll it, and looking before every long sleep cost the 128 x 50 kbp band pipeline 30 %
+        // (46 -> 61 ms), looking every 16 short spins cost config #2 35 %.  Every 8th long sleep (<= 0.9 ms between looks instead of
+        // the 28 ms ADVICE round 3 objected to) and every 256th short one cost nothing measurable.
+        if (((far > 0 && (spins & 7) == 7) || (spins & 255) == 255) &&
             __hip_atomic_load((const GlobalU32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         if (far > 0) { for (int i = 0; i < min(far, 32); ++i) __builtin_amdgcn_s_sleep(127); }
         else __builtin_amdgcn_s_sleep(2);

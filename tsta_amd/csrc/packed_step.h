@@ -222,10 +222,13 @@ __device__ __forceinline__ bool block_cannot_raise_max(const PLane<R>& s, const 
 // What the block computes from them moves by at most `per step` bounds the caller knows, so one look per block decides whether the
 // block may run with pkmax3f (operands inside [kF16Lo, kF16Hi]), must run with the two-instruction u16 maximum, or has left the
 // 16-bit window altogether.
+// th_real: this lane's top-row entry belongs to a real column (beyond the sequences' end the register holds whatever was loaded
+// last, which never reaches a real cell).
 template <int R>
-__device__ __forceinline__ void block_range(const PLane<R>& s, unsigned& lo, unsigned& hi)
+__device__ __forceinline__ void block_range(const PLane<R>& s, const bool th_real, unsigned& lo, unsigned& hi)
 {
-    lo = pkmin(s.hd, s.th); hi = pkmax(s.hd, s.th);
+    const unsigned thv = th_real ? s.th : s.hd;
+    lo = pkmin(s.hd, thv); hi = pkmax(s.hd, thv);
 #pragma unroll
     for (int k = 0; k < R; ++k) { lo = pkmin(lo, s.hl[k]); hi = pkmax(hi, s.hl[k]); }
 #pragma unroll

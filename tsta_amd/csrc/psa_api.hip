@@ -243,8 +243,10 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
     // F3: scores around 0x4000 so that a steady block's three-way maximum can be one v_pk_maximum3_f16 (psa_score_packed.hip); a couple
     // whose scores leave the 16-bit window on the way is handed to the int32 kernel through these flags
     const int f3 = couples ? tsta::psa_f16max_mode(*p, Rp ? Rp : Rb, e->opt_psa_f16max) : 0;
+    e->last_redo = nullptr; e->last_redo_n = 0;
     if (f3) {
         a.redo = reinterpret_cast<uint8_t*>(e->pair_flags.p) + n_pairs;
+        e->last_redo = a.redo; e->last_redo_n = n_pairs;
         if ((rc = e->check(hipMemsetAsync(a.redo, 0, (size_t)n_pairs, s), "hipMemsetAsync(redo flags)")) != TSTA_OK) return rc;
     }
     e->timing_begin(s);

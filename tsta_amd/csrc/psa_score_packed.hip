@@ -150,8 +150,9 @@ __device__ __forceinline__ bool pband(const uint8_t* __restrict__ aA, const uint
         if (F3) {
             // where does the block start from, and can 64 steps take it out of range?  Down: a step lowers a value by at most a mismatch
             // plus a gap open, intermediates by a gap extension more; up: only the free-free frame's diagonal adds (2|E|+M per step)
+            if (!steady && !elide && nA != nB) bound_garbage_columns<R, kBias>(s, t0, ln, nA, nB);   // (before the look: garbage halves at the bias)
             unsigned lo, hi;
-            block_range<R>(s, lo, hi);
+            block_range<R>(s, t0 + ln < n, lo, hi);
             const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
             const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
             const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;           // (+ the running max's column offset, <= 127 M)

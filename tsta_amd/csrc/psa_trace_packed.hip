@@ -316,8 +316,10 @@ __device__ __forceinline__ bool packed_tile(const CoupleView& V, const int s0, c
         if (elide) { const int v = eframe_top_shift<R>(F, ln); const unsigned pv = pack2(v, v); s.th = pkadd(s.th, pv); s.te = pkadd(s.te, pv); }
         bool fast = false;
         if (F3) {                                      // the block's range against what 64 steps can move it by (psa_score_packed.hip)
+            if (!steady && !elide && nA != nB) bound_garbage_columns<R, kBias>(s, t0, ln, nA, nB);   // (before the look: garbage halves at the bias)
             unsigned lo, hi;
-            block_range<R>(s, lo, hi);
+            block_range<R>(s, t0 + ln < n, lo, hi);            // (beyond both jobs' end the entry is loaded as 0: not a score; beyond ONE
+                                                               //  job's end its half was just set to the bias)
             const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
             const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
             const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;
