@@ -410,6 +410,7 @@ def main():
             if i:
                 walls.append(w); kms.append(eng.last_kernel_ms()[0])
         assert np.array_equal(got, resident), "end-to-end scores differ from the HBM-resident run's"
+        n_sub = eng.stat("last_sub_batches")
         my = [float(np.mean(walls)), float(np.mean(kms))]
         allw = [my]
         if world > 1:
@@ -429,7 +430,7 @@ def main():
         del h2
         wall_ms = max(r[0] for r in allw)
         e2e = {"value": float(P) * world * L * L / (wall_ms * 1e-3) / 1e9, "unit": "GCUPS", "wall_ms": wall_ms,
-               "kernel_ms": max(r[1] for r in allw), "steps": len(walls), "sub_batches": eng.stat("last_sub_batches"),
+               "kernel_ms": max(r[1] for r in allw), "steps": len(walls), "sub_batches": n_sub,
                "host_bytes_per_rank": int(h_seqs.nbytes), "scores_equal_resident_run": True, "two_shards_in_one_call": two,
                "note": "SURVEY 8(d) metric: host clock around tsta_psa_score_batch (pageable host shard in, scores on the host out; max "
                        "over ranks), kernel_ms = HIP events from the first sub-batch's first kernel to the last one's end; upload of "
