@@ -79,6 +79,127 @@ __device__ __forceinline__ int scan_max(int x, int lane)
     return x;
 }
 
+// the same two scans and the one-lane shift as VALU-only DPP (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 / :31
+// across them) instead of six ds_bpermute round trips each: the fast row below runs on a lone wave, where every LDS instruction costs
+// far more than an issue slot
+__device__ __forceinline__ int dpp_scan_add(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ int dpp_scan_max(int x)
+{
+    constexpr int kNeg = INT_MIN / 2;
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(kNeg, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+__device__ __forceinline__ int dpp_up1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+
+// tracker_step for a predecessor whose two reservoirs are empty (vc1 = vc2 = 0, the state every row with ONE predecessor starts from,
+// c-t-simd.c:339-346): v moves as before, vc1 stays 0, and the new vc2 is y — collected in `spill`; a row in which any lane's y was
+// non-zero is run again with the full tracker.
+__device__ __forceinline__ void tracker_step_empty(int best, int t, int& v, int& spill)
+{
+    int d = subs8(best, t);
+    const int vc0 = adds8(v, d);
+    d = max(d, 0);
+    spill |= subus8(d, subs8(127, v));
+    v = vc0;
+}
+
+// The row of a node with ONE predecessor at -W 10, every statement of the three sweeps below specialised for it: the predecessor's
+// bytes, the sequence characters and the lane state {v, f} live in registers (reservoirs empty: tracker_step_empty), the W loops are
+// unrolled, the scans are DPP.  Same arithmetic, statement for statement (c-t-simd.c:357-565 with pre_num = 1).  Returns false when a
+// reservoir would have filled: nothing of the row is final then and the caller runs the general sweeps.
+template <int W>
+struct RowBytes { int t[(W + 3) / 4], e[(W + 3) / 4]; };
+
+template <int W, class Mid>
+__device__ __forceinline__ bool row_one_fast(Mid&& mid, const RowBytes<W>& pr, const int rs_lane, const int v0, const int f0v, const int (&chr)[W],
+                                             const int base, const int M, const int X, const int E, const int O, const int lane,
+                                             RowBytes<W>& out, int& sum, int& f_last,
+                                             int8_t* __restrict__ src, int8_t* __restrict__ esrc, int8_t* __restrict__ fsrc, const int n_left)
+{
+    const int E8 = wrap8(E), OE8 = wrap8(O + E);
+    int v = lane == 0 ? v0 : E8, f = lane == 0 ? f0v : kSmin, spill = 0;
+    // ---- first pass (:357-404)
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int h = (chr[i] == base) ? M : X;
+        int t1 = max(max(f, h), byte_of(pr.e[i >> 2], i));
+        t1 = subs8(t1, v);
+        if (v > kLogoCut) t1 = OE8;
+        const int s1 = max(kSmin, t1);
+        const int t = byte_of(pr.t[i >> 2], i);
+        const int a = subs8(f, wrap8(t - E8));
+        const int c = adds8(v, subs8(adds8(s1, OE8), t));
+        f = max(a, c);
+        tracker_step_empty(s1, t, v, spill);
+    }
+    // ---- lazy F across the lanes, every lane's end state to its right neighbour (:406-446)
+    {
+        const bool mid = lane >= 1 && lane <= 62;
+        const int cx = mid ? W * E - rs_lane : 0;
+        const int C = dpp_scan_add(cx);
+        const int te = C + dpp_scan_max(f - C);
+        const int ftn = mid ? min(te, kFClamp) : f;
+        const int nv0 = max(subs8(ftn, E8), v);
+        const int f_up = dpp_up1(ftn), v_up = dpp_up1(nv0);
+        v = lane ? v_up : v0;                                  // adds8(.., nc1 = 0)
+        f = lane ? f_up : f0v;
+    }
+    mid();                                                     // (the caller's deferred publication of the previous row: its stores have long landed)
+    // ---- second pass (:447-565)
+    sum = 0;
+#pragma unroll
+    for (int q = 0; q < (W + 3) / 4; ++q) { out.t[q] = 0; out.e[q] = 0; }
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int ch = chr[i];
+        const int h = (ch == base) ? M : X;
+        const int t = byte_of(pr.t[i >> 2], i), e = byte_of(pr.e[i >> 2], i);
+        const int fv = subs8(f, v), eu = subs8(e, v), q = subs8(h, v), ev = subs8(e, t);
+        int c = max(max(fv, eu), q);
+        if (v > kLogoCut) c = OE8;
+        int best = max(kSmin, c);
+        const int eumax = max(kSmin, eu);
+        if (ch == 'N') best = 0;
+        sum = wrap8(sum + best);
+        const int open = adds8(best, OE8);
+        const bool j_eu = best == eu, j_q = best == q;
+        f = adds8(f, E8);
+        const int s1 = adds8(open, v);
+        const bool m1 = f == s1;
+        f = subs8(max(f, s1), t);
+        int fs = (fv == OE8) ? 2 : 1;
+        const int e2 = subs8(adds8(e, E8), v);
+        const int emax = max(kSmin, max(open, e2));
+        int es = 1;
+        if (eu == eumax) { es = (ev == OE8) ? 43 : 1; if (open == e2) es = -es; }
+        tracker_step_empty(best, t, v, spill);
+        if (m1) fs = -fs;
+        int code = 126;
+        if (j_eu) code = 0;
+        if (j_q && h == X) code = 84;
+        if (j_q && h == M) code = 42;
+        out.t[i >> 2] |= (best & 255) << ((i & 3) * 8);
+        out.e[i >> 2] |= (emax & 255) << ((i & 3) * 8);
+        if (src && i < n_left) { src[i] = (int8_t)code; esrc[i] = (int8_t)es; fsrc[i] = (int8_t)fs; }
+    }
+    f_last = __builtin_amdgcn_readlane(f, 63);               // row->f0 (:566-567): lane 63's F
+    return __builtin_amdgcn_readfirstlane((int)(__ballot(spill != 0) != 0ull)) == 0;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
@@ -106,6 +227,26 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
     for (int i = 0; i < W; ++i) { const int c0 = k * L + lane * W + i; sqc[i][lane] = c0 < n ? A.seq[c0] : (uint8_t)'N'; }
     const size_t blk_dw = (size_t)2 * Wq * 64;       // dwords of one (row, block) in P.rows
     int seen_left = 0;
+    // ---- round 4: what the fast row (row_one_fast, -W 10) keeps in registers across rows
+    constexpr int FW = 10;
+    const bool fastW = (W == FW);
+    int chr[FW];
+#pragma unroll
+    for (int i = 0; i < FW; ++i) chr[i] = fastW ? (int)sqc[i][lane] : 0;
+    RowBytes<FW> prev;                               // the previous row's bytes of this block (the backbone predecessor never goes through memory)
+#pragma unroll
+    for (int q = 0; q < (FW + 3) / 4; ++q) { prev.t[q] = 0; prev.e[q] = 0; }
+    int prev_r = -2, prev_sum = 0, prev_fc = 0, prev_simple_k = 0;
+    // A row's stores are drained and its progress published by the NEXT row: half-way through it when that row takes everything of this
+    // one from registers (the stores have long landed then: the s_waitcnt costs nothing), at its start when it reads rows of this block
+    // back from memory.  rows_done = rows of this block that are complete.
+    bool pending_pub = false;
+    auto flush_pub = [&](int rows_done) {
+        if (!pending_pub) return;
+        if (k + 1 < nblk && !mute) publish_progress(&P.prog[k], rows_done, lane);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pending_pub = false;
+    };
 
     for (int r = 0; r < V; ++r) {
         const int poff = A.pred_off[r];
@@ -120,9 +261,16 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         const bool first_task = bi <= P.lmaxtag && bl == bj - 1;          // :194
         const bool f0_init = first_task && bi < P.nrowblk;                // :263
 
+        const int pj0 = is_src ? V : A.pred[poff];
+        const bool one_fast = fastW && np == 1;
+        const bool from_prev = one_fast && !is_src && pj0 == prev_r;
+        if (!from_prev) flush_pub(r);              // (this row may read rows of this block back from memory)
+        RowBytes<FW> pr;
+        int rs_lane = 0;
+        if (from_prev) { pr = prev; rs_lane = prev_sum; }
         // ---- the predecessors' bytes of this block into LDS; their sums per lane (:279-288).  Rows of this block: nothing here
         // waits for the block on the left
-        for (int j = 0; j < np; ++j) {
+        for (int j = 0; j < np && !from_prev; ++j) {
             const int pj = is_src ? V : A.pred[poff + j];
             int sum = 0;
             for (int q = 0; q < Wq; ++q) {
@@ -136,9 +284,11 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                     tw = load_sc1_int(src); ew = load_sc1_int(src + (size_t)Wq * 64);
                 }
                 pt[(j * Wq + q) * 64 + lane] = tw; pe[(j * Wq + q) * 64 + lane] = ew;
+                if (one_fast && q < (FW + 3) / 4) { pr.t[q] = tw; pr.e[q] = ew; }
                 for (int i = 4 * q; i < min(W, 4 * q + 4); ++i) sum = wrap8(sum + byte_of(tw, i));
             }
             rs[j * 64 + lane] = sum;
+            rs_lane = sum;
         }
         // ---- the block on the left has finished this row (its running sum, its F carries); how far it is is remembered
         if (k > 0 && seen_left <= r) {
@@ -151,9 +301,11 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         const int pj_l = lane < np ? (is_src ? V : A.pred[poff + lane]) : -1;
         const bool has_p = lane < np && !is_src;
         int simple_rk = (k > 0) ? load_sc1_int(&P.simple[(size_t)r * (nblk + 1) + k]) : 0;
-        const int fcp = (has_p && first_task) ? load_sc1_int(&P.first_col[pj_l]) : INT_MIN / 2;
-        const int spk = (has_p && !first_task) ? load_sc1_int(&P.simple[(size_t)pj_l * (nblk + 1) + k]) : 0;
+        const bool p_prev = pj_l == prev_r;          // (what the previous row left is still in registers)
+        const int fcp = (has_p && first_task) ? ((p_prev && k == 0) ? prev_fc : load_sc1_int(&P.first_col[pj_l])) : INT_MIN / 2;
+        const int spk = (has_p && !first_task) ? (p_prev ? prev_simple_k : load_sc1_int(&P.simple[(size_t)pj_l * (nblk + 1) + k])) : 0;
         const int f0_in = (!f0_init && lane < np) ? load_sc1_int(&P.f0[(size_t)r * maxp + lane]) : 0;
+        int v0_b = 0, f0_b = 0, fc_row = E + O;      // lane 0's first-column v and F (a row with one predecessor needs nothing else); first_col of this row
         {
             int te = 0, v0 = 0, c1 = 0, c2 = 0;
             if (is_src) {                                                  // :174-188, :227-232
@@ -167,6 +319,7 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                 fc += E;
                 te = fc - fcp;
                 split_offset(te, v0, c1, c2);
+                fc_row = fc;
                 if (k == 0) {
                     simple_rk = fc;
                     if (lane == 0) { store_sc1_int(&P.first_col[r], fc); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], fc); }
@@ -176,8 +329,10 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                 split_offset(te, v0, c1, c2);
             }
             if (np == 1) { c1 = 0; c2 = 0; }                               // :339-346
+            const int f0v = f0_init ? wrap8(v0 + E + O) : f0_in;          // :263-271
             s_v0[lane] = v0; s_c1[lane] = c1; s_c2[lane] = c2; s_te[lane] = te;
-            s_f0[lane] = f0_init ? wrap8(v0 + E + O) : f0_in;              // :263-271
+            s_f0[lane] = f0v;
+            v0_b = __builtin_amdgcn_readfirstlane(v0); f0_b = __builtin_amdgcn_readfirstlane(f0v);
         }
         int sum = 0, f_last = 0;
         // the three sweeps over the row; ONE: a node with a single predecessor keeps its lane state in a register
@@ -298,11 +453,36 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
             if constexpr (ONE) f_last = __shfl(S1 >> 24, 63, 64);         // row->f0 (:566-567): lane 63's F
             else f_last = lane < np ? (st[lane * 64 + 63] >> 24) : 0;
         };
-        if (np == 1) sweeps(std::true_type{}); else sweeps(std::false_type{});
+        bool fast_done = false;
+        RowBytes<FW> ob;
+        if (one_fast) {
+            const int c0 = k * L + lane * FW;
+            int8_t* src = A.source ? A.source + (size_t)r * A.tpitch + c0 : nullptr;
+            int8_t* esrc = A.source ? A.esource + (size_t)r * A.tpitch + c0 : nullptr;
+            int8_t* fsrc = A.source ? A.fsource + (size_t)r * A.tpitch + c0 : nullptr;
+            int fl = 0;
+            fast_done = row_one_fast<FW>([&] { if (from_prev) flush_pub(r); }, pr, rs_lane, v0_b, f0_b, chr, base, M, X, E, O, lane,
+                                         ob, sum, fl, src, esrc, fsrc, n - c0);
+            if (fast_done) f_last = fl;               // (lane 0 stores it: one predecessor)
+            else if (from_prev) {                     // a reservoir filled: the general sweeps, from LDS as usual
+#pragma unroll
+                for (int q = 0; q < (FW + 3) / 4; ++q) { pt[q * 64 + lane] = pr.t[q]; pe[q * 64 + lane] = pr.e[q]; }
+                rs[lane] = rs_lane;
+            }
+            if (!fast_done) sum = 0;
+        }
+        if (!fast_done) {
+            if (np == 1) sweeps(std::true_type{}); else sweeps(std::false_type{});
+            if (fastW) {
+#pragma unroll
+                for (int q = 0; q < (FW + 3) / 4; ++q) { ob.t[q] = outb[0][q][lane]; ob.e[q] = outb[1][q][lane]; }
+            }
+        }
         // ---- what the row leaves: its bytes of this block, the F carries, the running sum (:568-575)
         for (int q = 0; q < Wq; ++q) {
             int* dst = P.rows + ((size_t)r * nblk + k) * blk_dw + (size_t)q * 64 + lane;
-            store_sc1_int(dst, outb[0][q][lane]); store_sc1_int(dst + (size_t)Wq * 64, outb[1][q][lane]);
+            if (fastW && q < (FW + 3) / 4) { store_sc1_int(dst, ob.t[q]); store_sc1_int(dst + (size_t)Wq * 64, ob.e[q]); }
+            else { store_sc1_int(dst, outb[0][q][lane]); store_sc1_int(dst + (size_t)Wq * 64, outb[1][q][lane]); }
         }
         if (lane < np) store_sc1_int(&P.f0[(size_t)r * maxp + lane], f_last);
         int red = sum;
@@ -313,11 +493,11 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
             store_sc1_int(&P.simple[(size_t)r * (nblk + 1) + k + 1], total);
             if (k == nblk - 1) A.lastscore[r] = total;
         }
-        // the row's stores have left before anything of the next row is loaded (later rows of this block read them back); the
-        // block on the right is told
-        if (k + 1 < nblk && !mute) publish_progress(&P.prog[k], r + 1, lane);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the row's stores are drained, and the block on the right told, by the next row (flush_pub)
+        if (fastW) { prev = ob; prev_r = r; prev_sum = sum; prev_fc = fc_row; prev_simple_k = simple_rk; }
+        pending_pub = true;
     }
+    flush_pub(V);
 }
 
 size_t poa_ref8_lds_bytes(int maxp, int Wq) { return (size_t)maxp * 64 * sizeof(int) * (2 * (size_t)Wq + 3); }
