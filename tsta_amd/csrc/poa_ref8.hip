@@ -66,22 +66,9 @@ __device__ __forceinline__ void split_offset(int te, int& v, int& c1, int& c2)
     } else { v = wrap8(te); c2 = 0; c1 = 0; }
 }
 
-__device__ __forceinline__ int scan_add(int x, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
-    return x;
-}
-__device__ __forceinline__ int scan_max(int x, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(x, off, 64); if (lane >= off) x = max(x, o); }
-    return x;
-}
-
-// the same two scans and the one-lane shift as VALU-only DPP (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 / :31
-// across them) instead of six ds_bpermute round trips each: the fast row below runs on a lone wave, where every LDS instruction costs
-// far more than an issue slot
+// the scans over the 64 byte lanes and the one-lane shift as VALU-only DPP (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then
+// row_bcast:15 / :31 across them) instead of six ds_bpermute round trips each: a block is a lone wave, for which an LDS instruction
+// costs far more than an issue slot
 __device__ __forceinline__ int dpp_scan_add(int x)
 {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
@@ -104,6 +91,10 @@ __device__ __forceinline__ int dpp_scan_max(int x)
     return x;
 }
 __device__ __forceinline__ int dpp_up1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ int scan_add(int x, int) { return dpp_scan_add(x); }      // inclusive prefix sum / maximum over the lanes
+__device__ __forceinline__ int scan_max(int x, int) { return dpp_scan_max(x); }
+// sum over the wave (every lane gets lane 63's inclusive prefix)
+__device__ __forceinline__ int wave_sum(int x) { return __builtin_amdgcn_readlane(dpp_scan_add(x), 63); }
 
 // tracker_step for a predecessor whose two reservoirs are empty (vc1 = vc2 = 0, the state every row with ONE predecessor starts from,
 // c-t-simd.c:339-346): v moves as before, vc1 stays 0, and the new vc2 is y — collected in `spill`; a row in which any lane's y was
@@ -124,7 +115,7 @@ __device__ __forceinline__ void tracker_step_empty(int best, int t, int& v, int&
 template <int W>
 struct RowBytes { int t[(W + 3) / 4], e[(W + 3) / 4]; };
 
-template <int W, class Mid>
+template <int W, bool ALLIN, class Mid>
 __device__ __forceinline__ bool row_one_fast(Mid&& mid, const RowBytes<W>& pr, const int rs_lane, const int v0, const int f0v, const int (&chr)[W],
                                              const int base, const int M, const int X, const int E, const int O, const int lane,
                                              RowBytes<W>& out, int& sum, int& f_last,
@@ -194,7 +185,8 @@ __device__ __forceinline__ bool row_one_fast(Mid&& mid, const RowBytes<W>& pr, c
         if (j_q && h == M) code = 42;
         out.t[i >> 2] |= (best & 255) << ((i & 3) * 8);
         out.e[i >> 2] |= (emax & 255) << ((i & 3) * 8);
-        if (src && i < n_left) { src[i] = (int8_t)code; esrc[i] = (int8_t)es; fsrc[i] = (int8_t)fs; }
+        if (ALLIN || i < n_left) { src[i] = (int8_t)code; esrc[i] = (int8_t)es; fsrc[i] = (int8_t)fs; }   // (ALLIN: the lane's W columns all exist
+                                                                                                       //  and the trace arrays are wanted: no branch)
     }
     f_last = __builtin_amdgcn_readlane(f, 63);               // row->f0 (:566-567): lane 63's F
     return __builtin_amdgcn_readfirstlane((int)(__ballot(spill != 0) != 0ull)) == 0;
@@ -264,13 +256,34 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         const int pj0 = is_src ? V : A.pred[poff];
         const bool one_fast = fastW && np == 1;
         const bool from_prev = one_fast && !is_src && pj0 == prev_r;
-        if (!from_prev) flush_pub(r);              // (this row may read rows of this block back from memory)
+        // (-W 10: the previous row is taken from registers wherever it is a predecessor, every older row's stores were drained half-way
+        //  through the previous row: nothing to wait for here.  Other -W: rows of this block are read back from memory)
+        if (!fastW) flush_pub(r);
         RowBytes<FW> pr;
         int rs_lane = 0;
         if (from_prev) { pr = prev; rs_lane = prev_sum; }
+        else if (one_fast) {                       // the one predecessor's bytes straight into registers (constant indices: no scratch)
+            int sm = 0;
+#pragma unroll
+            for (int q = 0; q < (FW + 3) / 4; ++q) {
+                int tw, ew;
+                if (pj0 == V) {                                            // the virtual first row (:82-94; its first byte :176-185)
+                    const int t0 = (bi == 0) ? wrap8(O + E) : E8, e0 = (bi == 0) ? wrap8(2 * (O + E)) : wrap8(E + O + E);
+                    tw = pack4(E8, E8, E8, E8); ew = pack4(wrap8(E + E + O), wrap8(E + E + O), wrap8(E + E + O), wrap8(E + E + O));
+                    if (q == 0 && lane == 0) { tw = (tw & ~255) | (t0 & 255); ew = (ew & ~255) | (e0 & 255); }
+                } else {
+                    const int* src = P.rows + ((size_t)pj0 * nblk + k) * blk_dw + (size_t)q * 64 + lane;
+                    tw = load_sc1_int(src); ew = load_sc1_int(src + (size_t)Wq * 64);
+                }
+                pr.t[q] = tw; pr.e[q] = ew;
+#pragma unroll
+                for (int i = 4 * q; i < (4 * q + 4 < FW ? 4 * q + 4 : FW); ++i) sm = wrap8(sm + byte_of(tw, i));
+            }
+            rs_lane = sm;
+        }
         // ---- the predecessors' bytes of this block into LDS; their sums per lane (:279-288).  Rows of this block: nothing here
         // waits for the block on the left
-        for (int j = 0; j < np && !from_prev; ++j) {
+        for (int j = 0; j < np && !one_fast; ++j) {
             const int pj = is_src ? V : A.pred[poff + j];
             int sum = 0;
             for (int q = 0; q < Wq; ++q) {
@@ -279,16 +292,17 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                     const int t0 = (bi == 0) ? wrap8(O + E) : E8, e0 = (bi == 0) ? wrap8(2 * (O + E)) : wrap8(E + O + E);
                     tw = pack4(E8, E8, E8, E8); ew = pack4(wrap8(E + E + O), wrap8(E + E + O), wrap8(E + E + O), wrap8(E + E + O));
                     if (q == 0 && lane == 0) { tw = (tw & ~255) | (t0 & 255); ew = (ew & ~255) | (e0 & 255); }
+                } else if (fastW && pj == prev_r) {                        // the row just finished: still in registers (its stores may be under way)
+                    tw = q == 0 ? prev.t[0] : (q == 1 ? prev.t[1] : prev.t[2]);
+                    ew = q == 0 ? prev.e[0] : (q == 1 ? prev.e[1] : prev.e[2]);
                 } else {
                     const int* src = P.rows + ((size_t)pj * nblk + k) * blk_dw + (size_t)q * 64 + lane;
                     tw = load_sc1_int(src); ew = load_sc1_int(src + (size_t)Wq * 64);
                 }
                 pt[(j * Wq + q) * 64 + lane] = tw; pe[(j * Wq + q) * 64 + lane] = ew;
-                if (one_fast && q < (FW + 3) / 4) { pr.t[q] = tw; pr.e[q] = ew; }
                 for (int i = 4 * q; i < min(W, 4 * q + 4); ++i) sum = wrap8(sum + byte_of(tw, i));
             }
             rs[j * 64 + lane] = sum;
-            rs_lane = sum;
         }
         // ---- the block on the left has finished this row (its running sum, its F carries); how far it is is remembered
         if (k > 0 && seen_left <= r) {
@@ -314,8 +328,11 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                 if (k == 0 && lane == 0) { store_sc1_int(&P.first_col[r], E + O); store_sc1_int(&P.simple[(size_t)r * (nblk + 1)], E + O); }
             } else if (first_task) {                                       // :194-224
                 int fc = fcp;
+                if (np == 1) fc = __builtin_amdgcn_readfirstlane(fcp);      // (lanes beyond the predecessors hold minus infinity)
+                else {
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) fc = max(fc, __shfl_xor(fc, off, 64));
+                    for (int off = 32; off >= 1; off >>= 1) fc = max(fc, __shfl_xor(fc, off, 64));
+                }
                 fc += E;
                 te = fc - fcp;
                 split_offset(te, v0, c1, c2);
@@ -391,10 +408,11 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                 const int te = C + scan_max(ft - C, lane);                 // te_x = max(te_{x-1} + c_x, ft_x)
                 const int ftn = mid ? min(te, kFClamp) : ft;
                 const int nv0 = max(subs8(ftn, E8), v);
-                const int f_up = __shfl_up(ftn, 1, 64), v_up = __shfl_up(nv0, 1, 64), c1_up = __shfl_up(c1, 1, 64), c2_up = __shfl_up(c2, 1, 64);
+                const int f_up = dpp_up1(ftn), v_up = dpp_up1(nv0), c1_up = dpp_up1(c1), c2_up = dpp_up1(c2);
                 const int nc1 = lane ? c1_up : s_c1[j], nc2 = lane ? c2_up : s_c2[j];
                 sd(j, pack4(adds8(lane ? v_up : s_v0[j], nc1), nc1, nc2, lane ? f_up : s_f0[j]));
             }
+            flush_pub(r);                          // (the previous row's stores have long landed: see flush_pub)
             // ---- second pass (:447-565)
             for (int i = 0; i < W; ++i) {
                 const int ch = sqc[i][lane];
@@ -461,10 +479,15 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
             int8_t* esrc = A.source ? A.esource + (size_t)r * A.tpitch + c0 : nullptr;
             int8_t* fsrc = A.source ? A.fsource + (size_t)r * A.tpitch + c0 : nullptr;
             int fl = 0;
-            fast_done = row_one_fast<FW>([&] { if (from_prev) flush_pub(r); }, pr, rs_lane, v0_b, f0_b, chr, base, M, X, E, O, lane,
-                                         ob, sum, fl, src, esrc, fsrc, n - c0);
+            auto mid = [&] { flush_pub(r); };
+            // (whole wave inside the sequence and trace arrays wanted: the stores need no per-column test; a wave-uniform choice)
+            if (A.source && k * L + 64 * FW <= n)
+                fast_done = row_one_fast<FW, true>(mid, pr, rs_lane, v0_b, f0_b, chr, base, M, X, E, O, lane, ob, sum, fl, src, esrc, fsrc, FW);
+            else
+                fast_done = row_one_fast<FW, false>(mid, pr, rs_lane, v0_b, f0_b, chr, base, M, X, E, O, lane, ob, sum, fl, src, esrc, fsrc,
+                                                    A.source ? n - c0 : 0);
             if (fast_done) f_last = fl;               // (lane 0 stores it: one predecessor)
-            else if (from_prev) {                     // a reservoir filled: the general sweeps, from LDS as usual
+            else {                                    // a reservoir filled: the general sweeps, from LDS as usual
 #pragma unroll
                 for (int q = 0; q < (FW + 3) / 4; ++q) { pt[q * 64 + lane] = pr.t[q]; pe[q * 64 + lane] = pr.e[q]; }
                 rs[lane] = rs_lane;
@@ -479,15 +502,20 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
             }
         }
         // ---- what the row leaves: its bytes of this block, the F carries, the running sum (:568-575)
-        for (int q = 0; q < Wq; ++q) {
-            int* dst = P.rows + ((size_t)r * nblk + k) * blk_dw + (size_t)q * 64 + lane;
-            if (fastW && q < (FW + 3) / 4) { store_sc1_int(dst, ob.t[q]); store_sc1_int(dst + (size_t)Wq * 64, ob.e[q]); }
-            else { store_sc1_int(dst, outb[0][q][lane]); store_sc1_int(dst + (size_t)Wq * 64, outb[1][q][lane]); }
+        if (fastW) {
+#pragma unroll
+            for (int q = 0; q < (FW + 3) / 4; ++q) {
+                int* dst = P.rows + ((size_t)r * nblk + k) * blk_dw + (size_t)q * 64 + lane;
+                store_sc1_int(dst, ob.t[q]); store_sc1_int(dst + (size_t)Wq * 64, ob.e[q]);
+            }
+        } else {
+            for (int q = 0; q < Wq; ++q) {
+                int* dst = P.rows + ((size_t)r * nblk + k) * blk_dw + (size_t)q * 64 + lane;
+                store_sc1_int(dst, outb[0][q][lane]); store_sc1_int(dst + (size_t)Wq * 64, outb[1][q][lane]);
+            }
         }
         if (lane < np) store_sc1_int(&P.f0[(size_t)r * maxp + lane], f_last);
-        int red = sum;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) red += __shfl_xor(red, off, 64);
+        const int red = wave_sum(sum);
         const int total = simple_rk + (int)(int16_t)red;
         if (lane == 0) {
             store_sc1_int(&P.simple[(size_t)r * (nblk + 1) + k + 1], total);
