@@ -54,6 +54,7 @@ if fe and wr:
                        "bytes are 0.82 GB per launch",
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                     "--no-cpu-baseline --no-generic (separate passes)"}
+    t["_build"] = open(os.path.join(base, "build_info.txt")).read().split()[1] if os.path.exists(os.path.join(base, "build_info.txt")) else None
     json.dump(t, open(os.path.join(out, "traffic_psa_score.json"), "w"), indent=1)
 # HBM traffic of the configs' dominant kernels (bench_configs.py 2 3 4 5t under separate FETCH_SIZE / WRITE_SIZE passes):
 # profiles/traffic_configs.json, read by bench_configs.py for roofline.traffic
@@ -128,11 +129,13 @@ if c1.get("SQ_INSTS_VALU"):
                     "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generic "
                     "--no-related --no-verify   (second pass: GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR "
                     "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS)"}
+    v["_build"] = open(os.path.join(base, "build_info.txt")).read().split()[1] if os.path.exists(os.path.join(base, "build_info.txt")) else None
     json.dump(v, open(os.path.join(out, "valu_psa_score.json"), "w"), indent=1)
 for name in ("cell_microbench", "valu_microbench", "step_microbench"):
     if os.path.exists(os.path.join(base, name + ".txt")):
         shutil.copy(os.path.join(base, name + ".txt"), os.path.join(out, "%s_%s.txt" % (tag, name)))
-for f, name in (("bench_default.json", "bench_default"), ("bench_prof.json", "bench_under_rocprof"), ("configs.jsonl", "configs")):
+for f, name in (("bench_default.json", "bench_default"), ("bench_prof.json", "bench_under_rocprof"), ("configs.jsonl", "configs"),
+                ("side_timings.txt", "side_timings")):
     if os.path.exists(os.path.join(base, f)):
         shutil.copy(os.path.join(base, f), os.path.join(out, "%s_%s.%s" % (tag, name, f.split(".")[-1])))
 print(sorted(os.listdir(out)))
