@@ -192,6 +192,123 @@ __device__ __forceinline__ bool row_one_fast(Mid&& mid, const RowBytes<W>& pr, c
     return __builtin_amdgcn_readfirstlane((int)(__ballot(spill != 0) != 0ull)) == 0;
 }
 
+// The row of a node with NP = 2 .. 4 predecessors at -W 10 in the same register form (round 4): the general sweeps of the kernel below
+// (c-t-simd.c:290-565), statement for statement, with the per-predecessor lane state {v, vc1, vc2, f}, the predecessors' bytes and
+// the per-column temporaries in registers instead of LDS, the W and predecessor loops unrolled, the full tracker (the reservoirs of
+// such a row are not empty at its start).  fc_*: the block's first-column values per predecessor (what the kernel keeps in s_v0 ...).
+template <int W, int NP, bool ALLIN, class Mid>
+__device__ __forceinline__ void row_multi_fast(Mid&& mid, const RowBytes<W> (&pr)[NP], const int (&rs)[NP],
+                                               const int (&fc_v0)[NP], const int (&fc_c1)[NP], const int (&fc_c2)[NP], const int (&fc_te)[NP],
+                                               const int (&fc_f0)[NP], const int (&chr)[W],
+                                               const int base, const int M, const int X, const int E, const int O, const int lane,
+                                               RowBytes<W>& out, int& sum, int (&f_last)[NP],
+                                               int8_t* __restrict__ src, int8_t* __restrict__ esrc, int8_t* __restrict__ fsrc, const int n_left)
+{
+    const int E8 = wrap8(E), OE8 = wrap8(O + E);
+    int v[NP], c1[NP], c2[NP], f[NP];
+    // ---- what every lane starts its first pass with (:290-356)
+    {
+        int te[NP], m1 = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int x = W * E - rs[j];
+            te[j] = fc_te[j] + dpp_scan_add(x) - x;              // te_j at the start of lane b, under the guess that this row falls by E per column
+            m1 = min(m1, te[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            split_offset(te[j] + kLogoLow - m1, v[j], c1[j], c2[j]);
+            if (lane == 0) { v[j] = fc_v0[j]; c1[j] = fc_c1[j]; c2[j] = fc_c2[j]; }
+            f[j] = lane == 0 ? fc_f0[j] : kSmin;
+        }
+    }
+    // ---- first pass (:357-404)
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int h = (chr[i] == base) ? M : X;
+        int s1 = kSmin;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            int t = max(max(f[j], h), byte_of(pr[j].e[i >> 2], i));
+            t = subs8(t, v[j]);
+            if (v[j] > kLogoCut) t = OE8;
+            s1 = max(s1, t);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int t = byte_of(pr[j].t[i >> 2], i);
+            const int a = subs8(f[j], wrap8(t - E8));
+            const int c = adds8(v[j], subs8(adds8(s1, OE8), t));
+            f[j] = wrap8(max(a, c));
+            tracker_step(s1, t, v[j], c1[j], c2[j]);
+        }
+    }
+    // ---- lazy F across the lanes and the hand-over of every lane's end state to its right neighbour (:406-446)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int ft = f[j];
+        const bool mid_lane = lane >= 1 && lane <= 62;
+        const int cx = mid_lane ? W * E - rs[j] : 0;
+        const int C = dpp_scan_add(cx);
+        const int te = C + dpp_scan_max(ft - C);                 // te_x = max(te_{x-1} + c_x, ft_x)
+        const int ftn = mid_lane ? min(te, kFClamp) : ft;
+        const int nv0 = max(subs8(ftn, E8), v[j]);
+        const int f_up = dpp_up1(ftn), v_up = dpp_up1(nv0), c1_up = dpp_up1(c1[j]), c2_up = dpp_up1(c2[j]);
+        const int nc1 = lane ? c1_up : fc_c1[j], nc2 = lane ? c2_up : fc_c2[j];
+        v[j] = adds8(lane ? v_up : fc_v0[j], nc1); c1[j] = nc1; c2[j] = nc2; f[j] = wrap8(lane ? f_up : fc_f0[j]);
+    }
+    mid();
+    // ---- second pass (:447-565)
+    sum = 0;
+#pragma unroll
+    for (int q = 0; q < (W + 3) / 4; ++q) { out.t[q] = 0; out.e[q] = 0; }
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int ch = chr[i];
+        const int h = (ch == base) ? M : X;
+        int fv[NP], eu[NP], qd[NP], ev[NP];
+        int best = kSmin, eumax = kSmin;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int t = byte_of(pr[j].t[i >> 2], i), e = byte_of(pr[j].e[i >> 2], i);
+            fv[j] = subs8(f[j], v[j]); eu[j] = subs8(e, v[j]); qd[j] = subs8(h, v[j]); ev[j] = subs8(e, t);
+            int c = max(max(fv[j], eu[j]), qd[j]);
+            if (v[j] > kLogoCut) c = OE8;
+            best = max(best, c); eumax = max(eumax, eu[j]);
+        }
+        if (ch == 'N') best = 0;
+        sum = wrap8(sum + best);
+        const int open = adds8(best, OE8);
+        int es = 1, fs = 1, m1 = 0, emax = kSmin, j_eu = -1, j_q = -1;
+#pragma unroll
+        for (int j = NP - 1; j >= 0; --j) {
+            const int t = byte_of(pr[j].t[i >> 2], i), e = byte_of(pr[j].e[i >> 2], i);
+            if (best == eu[j]) j_eu = j;                          // lowest j wins (:485-506)
+            if (best == qd[j]) j_q = j;
+            int fj = adds8(f[j], E8);
+            const int s1 = adds8(open, v[j]);
+            m1 = (fj == s1);
+            fj = subs8(max(fj, s1), t);
+            if (fv[j] == OE8) fs = 2;
+            const int e2 = subs8(adds8(e, E8), v[j]);
+            emax = max(emax, max(open, e2));
+            if (eu[j] == eumax) { es = wrap8(((ev[j] == OE8) ? 43 : 1) + j); if (open == e2) es = wrap8(-es); }
+            tracker_step(best, t, v[j], c1[j], c2[j]);
+            f[j] = fj;
+        }
+        if (m1) fs = wrap8(-fs);
+        int code = 126;
+        if (j_eu >= 0) code = j_eu;
+        if (j_q >= 0 && h == X) code = 84 + j_q;
+        if (j_q >= 0 && h == M) code = 42 + j_q;
+        out.t[i >> 2] |= (best & 255) << ((i & 3) * 8);
+        out.e[i >> 2] |= (emax & 255) << ((i & 3) * 8);
+        if (ALLIN || i < n_left) { src[i] = (int8_t)code; esrc[i] = (int8_t)es; fsrc[i] = (int8_t)fs; }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) f_last[j] = __builtin_amdgcn_readlane(f[j], 63);   // row->f0 (:566-567): lane 63's F per predecessor
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
@@ -255,6 +372,7 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
 
         const int pj0 = is_src ? V : A.pred[poff];
         const bool one_fast = fastW && np == 1;
+        const bool multi_fast = fastW && (np == 2 || np == 3);   // row_multi_fast<10, np>
         const bool from_prev = one_fast && !is_src && pj0 == prev_r;
         // (-W 10: the previous row is taken from registers wherever it is a predecessor, every older row's stores were drained half-way
         //  through the previous row: nothing to wait for here.  Other -W: rows of this block are read back from memory)
@@ -283,7 +401,31 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         }
         // ---- the predecessors' bytes of this block into LDS; their sums per lane (:279-288).  Rows of this block: nothing here
         // waits for the block on the left
-        for (int j = 0; j < np && !one_fast; ++j) {
+        RowBytes<FW> prm[3];
+        int rsm[3] = {0, 0, 0};
+        if (multi_fast) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < np) {
+                    const int pj = A.pred[poff + j];
+                    int sm = 0;
+#pragma unroll
+                    for (int q = 0; q < (FW + 3) / 4; ++q) {
+                        int tw, ew;
+                        if (pj == prev_r) { tw = prev.t[q]; ew = prev.e[q]; }           // the row just finished: still in registers
+                        else {
+                            const int* src = P.rows + ((size_t)pj * nblk + k) * blk_dw + (size_t)q * 64 + lane;
+                            tw = load_sc1_int(src); ew = load_sc1_int(src + (size_t)Wq * 64);
+                        }
+                        prm[j].t[q] = tw; prm[j].e[q] = ew;
+#pragma unroll
+                        for (int i = 4 * q; i < (4 * q + 4 < FW ? 4 * q + 4 : FW); ++i) sm = wrap8(sm + byte_of(tw, i));
+                    }
+                    rsm[j] = sm;
+                }
+            }
+        }
+        for (int j = 0; j < np && !one_fast && !multi_fast; ++j) {
             const int pj = is_src ? V : A.pred[poff + j];
             int sum = 0;
             for (int q = 0; q < Wq; ++q) {
@@ -493,6 +635,31 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
                 rs[lane] = rs_lane;
             }
             if (!fast_done) sum = 0;
+        }
+        if (multi_fast) {
+            const int c0 = k * L + lane * FW;
+            int8_t* src = A.source ? A.source + (size_t)r * A.tpitch + c0 : nullptr;
+            int8_t* esrc = A.source ? A.esource + (size_t)r * A.tpitch + c0 : nullptr;
+            int8_t* fsrc = A.source ? A.fsource + (size_t)r * A.tpitch + c0 : nullptr;
+            auto mid = [&] { flush_pub(r); };
+            const bool allin = A.source && k * L + 64 * FW <= n;
+            const int nl = A.source ? n - c0 : 0;
+            auto run = [&](auto np_c) {
+                constexpr int NP = decltype(np_c)::value;
+                RowBytes<FW> prj[NP]; int rsj[NP], a_v0[NP], a_c1[NP], a_c2[NP], a_te[NP], a_f0[NP], fl[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    prj[j] = prm[j]; rsj[j] = rsm[j];
+                    a_v0[j] = s_v0[j]; a_c1[j] = s_c1[j]; a_c2[j] = s_c2[j]; a_te[j] = s_te[j]; a_f0[j] = s_f0[j];
+                }
+                if (allin) row_multi_fast<FW, NP, true>(mid, prj, rsj, a_v0, a_c1, a_c2, a_te, a_f0, chr, base, M, X, E, O, lane, ob, sum, fl, src, esrc, fsrc, FW);
+                else       row_multi_fast<FW, NP, false>(mid, prj, rsj, a_v0, a_c1, a_c2, a_te, a_f0, chr, base, M, X, E, O, lane, ob, sum, fl, src, esrc, fsrc, nl);
+                f_last = 0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) if (lane == j) f_last = fl[j];
+            };
+            if (np == 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 3>{});
+            fast_done = true;
         }
         if (!fast_done) {
             if (np == 1) sweeps(std::true_type{}); else sweeps(std::false_type{});

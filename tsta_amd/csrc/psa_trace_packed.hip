@@ -482,7 +482,7 @@ __global__ void psa_trace_packed_finish_kernel(const TraceJob* jobs, const Trace
 // tiles d-major, a wave waits for the band's previous tile and the upper band's tile 64 steps further, runs the tile with sc1
 // loads / stores of rows and lane state, publishes.
 template <int R, bool PERSIST, bool F3>
-__global__ __launch_bounds__(256) void psa_score_bands_kernel(PsaBandsArgs P)
+__global__ __launch_bounds__(256, (R == 16 ? 3 : 4)) void psa_score_bands_kernel(PsaBandsArgs P)
 {
     constexpr int NS = packed_state_ints(R);
     const PsaBatchArgs& A = P.b;
@@ -596,6 +596,8 @@ void launch_psa_score_bands_persistent(int R, const PsaBandsArgs& args, int n_cu
     hipError_t e = (R == 16) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<16, true, true>, 256, 0)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psa_score_bands_kernel<8, true, true>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
+    // two workgroups per CU = two waves per SIMD: more resident waves only lengthen the pipeline's skew (measured in round 4 on
+    // config #2 / 128 x 50 kbp: 3 per CU 4.41 / 51.2 ms, 4 per CU 4.56 / 51.5 ms against 4.16 / 40.5 — a SIMD serves its waves oldest-first)
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(((int64_t)args.n_tiles + 3) / 4, (int64_t)n_cu * std::min(nb, 2)));
     if (R == 16) { if (f3) hipLaunchKernelGGL((psa_score_bands_kernel<16, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args);
                    else    hipLaunchKernelGGL((psa_score_bands_kernel<16, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args); }
