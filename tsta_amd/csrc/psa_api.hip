@@ -62,8 +62,10 @@ static int psa_f16max_mode(const tsta_params& p, int R, int opt)
     if (opt >= 2) return opt - 1;
     const int64_t ae = -(int64_t)p.E, ao = -(int64_t)p.O, M = p.M, mx = (int64_t)p.M - p.X;
     const int64_t spread = (64LL * R + 256) * (M + ae) + 2 * ao;
-    const int64_t margins = 66 * (mx + ao + 2 * ae + M) + 66 * (2 * ae + M) + 130 * M;
-    return spread + margins < 15000 ? 1 : 0;
+    // the kernel's per-block margins (psa_score_packed.hip): 64 steps of drift, the next re-anchoring, a change of frame
+    const int64_t between = 64 * (ao + ae + M) + 64 * (ae + M) + 32 * (ae * R + ae + M) + ae * R + 64 * (ae + M);
+    const int64_t margin = std::max(66 * (mx + ao + 2 * ae + M), 66 * (2 * ae + M) + 130 * M) + between;
+    return spread + margin < 15000 ? 1 : 0;
 }
 
 // K1b (band pipeline over the couples of a batch, psa_trace_packed.hip: psa_score_bands_kernel) pays when K1p could

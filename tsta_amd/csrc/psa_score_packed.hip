@@ -85,6 +85,13 @@ __device__ __forceinline__ bool pband(const uint8_t* __restrict__ aA, const uint
         const int hd = hcol0p(i0, E, O);
         s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
     }
+    if (F3) {
+        // the column-0 values just packed are exact ints: did they fit 16 bits at all?  (they fall by |E| per row from the band's top row;
+        // a value that wrapped would look like a legitimate high one to the per-block look below)
+        const int top = hcol0p(i0, E, O), bot = hcol0p(i0 + R, E, O) + O;      // highest / lowest of this lane's hd, hl[], fb[]
+        const int lo_i = min(bot - acc.baseA, bot - acc.baseB) + kBias, hi_i = max(top - acc.baseA, top - acc.baseB) + kBias;
+        if (__ballot(lo_i < 0 || hi_i > 0xffff) != 0ull) return false;
+    }
     s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.sh = s.hbot; s.se = s.hbot; s.mx = 0u;
     s.cch2 = 0u; s.ach2 = 0u;
     const unsigned k4 = (pmx_s & 0xffu) * 0x01010101u;
@@ -155,7 +162,12 @@ __device__ __forceinline__ bool pband(const uint8_t* __restrict__ aA, const uint
             block_range<R>(s, t0 + ln < n, lo, hi);
             const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
             const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
-            const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;           // (+ the running max's column offset, <= 127 M)
+            // ... and what happens to every value BETWEEN this look and the next one: the next block's re-anchoring shifts by the top
+            // row's change over 64 columns (at most |O| + |E| + M per column, plus 64 columns of the elided frame's tilt), a change of
+            // frame adds the lane / row / column parts of elided_frame.  All of it inside the margins: no packed add can wrap unseen.
+            const int reanchor = 64 * ((int)(po_s & 0xffffu) + ae + M) + 64 * max(ae, ae + M);
+            const int reframe = 32 * abs(F.lane_coeff(R)) + ae * R + 64 * abs(F.col);
+            const int mdn = 66 * dm + reanchor + reframe, mup = 66 * (2 * ae + M) + 130 * M + reanchor + reframe;           // (+ the running max's column offset, <= 127 M)
             if (lo_min < mdn || hi_max > 0xffff - mup || f3_mode == 3) return false;   // leaves the 16-bit window: the int32 kernel takes the couple
             fast = f3_mode != 2 && lo_min >= (int)kF16Lo + mdn && hi_max <= (int)kF16Hi - mup;
         }

@@ -236,6 +236,11 @@ __device__ __forceinline__ bool packed_tile(const CoupleView& V, const int s0, c
         }
         const int hd = hcol0p(i0, E, O);
         s.hd = pack2(hd - acc.baseA + kBias, hd - acc.baseB + kBias);
+        if (F3) {                                     // (as in psa_score_packed.hip: the exact column-0 values must fit 16 bits)
+            const int bot = hcol0p(i0 + R, E, O) + O;
+            const int lo_i = min(bot - acc.baseA, bot - acc.baseB) + kBias, hi_i = max(hd - acc.baseA, hd - acc.baseB) + kBias;
+            if (__ballot(lo_i < 0 || hi_i > 0xffff) != 0ull) in_window = false;
+        }
         s.hbot = pack2(kBias, kBias); s.ebot = s.hbot; s.cch = 0u; s.cch2 = 0u;
     } else {
         auto ld = [&](int idx) -> int { return PERSIST ? load_sc1_int(&st[idx * 64]) : st[idx * 64]; };
@@ -322,7 +327,12 @@ __device__ __forceinline__ bool packed_tile(const CoupleView& V, const int s0, c
                                                                //  job's end its half was just set to the bias)
             const int lo_min = min((int)(lo & 0xffffu), (int)(lo >> 16)), hi_max = max((int)(hi & 0xffffu), (int)(hi >> 16));
             const int dm = (int)(pmx_s & 0xffffu) + (int)(po_s & 0xffffu) + 2 * ae + M;
-            const int mdn = 66 * dm, mup = 66 * (2 * ae + M) + 130 * M;
+            // ... and what happens to every value BETWEEN this look and the next one: the next block's re-anchoring shifts by the top
+            // row's change over 64 columns (at most |O| + |E| + M per column, plus 64 columns of the elided frame's tilt), a change of
+            // frame adds the lane / row / column parts of elided_frame.  All of it inside the margins: no packed add can wrap unseen.
+            const int reanchor = 64 * ((int)(po_s & 0xffffu) + ae + M) + 64 * max(ae, ae + M);
+            const int reframe = 32 * abs(F.lane_coeff(R)) + ae * R + 64 * abs(F.col);
+            const int mdn = 66 * dm + reanchor + reframe, mup = 66 * (2 * ae + M) + 130 * M + reanchor + reframe;
             if (lo_min < mdn || hi_max > 0xffff - mup || f3_mode == 3) in_window = false;   // (the tile is finished all the same: its
             fast = in_window && f3_mode != 2 && lo_min >= (int)kF16Lo + mdn && hi_max <= (int)kF16Hi - mup;   //  dependants must not wait)
         }
