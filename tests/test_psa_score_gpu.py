@@ -355,6 +355,7 @@ def test_fuzz_packed_vs_int32_vs_oracle(eng):
                     b = _fixed_len(a, m, k)
                 pairs.append((a, b))
             res = {}
+            eng.set_option("psa_f16max", 2 if trial % 2 else 1)     # every other trial: the binary16-order kernel whatever the host's estimate says
             for mode in (0, 32, 16, 8):
                 eng.set_option("psa_packed", mode)
                 res[mode] = eng.psa_score_batch(pairs, prm)
@@ -369,7 +370,7 @@ def test_fuzz_packed_vs_int32_vs_oracle(eng):
             if trial % 8 == 0:
                 assert np.array_equal(res[0], util.oracle_maxscore_batch(pairs, M=M, X=X, E=E, O=O)), (trial, M, X, E, O)
     finally:
-        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1)
+        eng.set_option("psa_packed", -1); eng.set_option("psa_bands", -1); eng.set_option("psa_f16max", 1)
 
 
 @pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=4, X=-6, E=-3, O=-5),

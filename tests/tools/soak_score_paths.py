@@ -33,11 +33,17 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
         pairs.append((a, b))
     eng.set_option("psa_packed", 0); eng.set_option("psa_bands", 0)
     ref = eng.psa_score_batch(pairs, prm)
+    # round 4: the binary16-order maximum (F3) — 1: where the host's estimate allows, 2: always (its per-block range proof and the
+    # int32 redo path then carry the exactness), 0: the round-3 kernels
+    f16 = (1, 2, 0)[trial % 3]
+    eng.set_option("psa_f16max", f16)
+    redo = 0
     for packed, bands, elide, perm, ffree in [(32, -1, 1, 1, 1), (32, -1, 1, 1, 0), (32, -1, 0, 0, 0), (16, -1, 1, 1, 1), (8, -1, 1, 0, 1), (-1, 8, 1, 1, 1), (-1, 16, 1, 1, 1), (-1, 16, 1, 1, 0), (-1, 16, 0, 0, 0), (-1, -1, 1, 1, 1)]:
         eng.set_option("psa_packed", packed); eng.set_option("psa_bands", bands); eng.set_option("psa_elide", elide); eng.set_option("psa_perm", perm); eng.set_option("psa_ffree", ffree)
         got = eng.psa_score_batch(pairs, prm)
+        redo = max(redo, eng.stat("psa_redo_pairs"))
         if not np.array_equal(got, ref):
             bad += 1
             print("MISMATCH", trial, (M, X, E, O), (packed, bands, elide, perm, ffree), np.nonzero(got != ref)[0].tolist(), flush=True)
-    print("trial", trial, (M, X, E, O), "ok" if not bad else "BAD", "%.0f s" % (time.time() - t0), flush=True)
+    print("trial", trial, (M, X, E, O), "f16max", f16, "redo pairs (max over paths)", redo, "ok" if not bad else "BAD", "%.0f s" % (time.time() - t0), flush=True)
 print("mismatches:", bad)

@@ -274,7 +274,10 @@ int psa_score_batch_dev_impl(Engine* e, const tsta_params* p, int64_t n_pairs, c
                                d_seqs, d_off1, d_len1, d_off2, d_len2, n_pairs, reinterpret_cast<uint8_t*>(e->pair_flags.p));
             ++launches;
         }
-        ba.T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : (max_len >= 16384 ? 128 : 64);
+        // tile length: 128 steps (round 4, with the cheaper F3 step the per-tile work — lane state in and out, waits, ticket — weighs more:
+        // config #2 at 64 / 128 / 192 / 256 steps 4.10 / 3.84 / 3.87 / 3.89 ms, 128 x 50 kbp at 128 / 256 / 512 40.7 / 41.2 / 44.6 ms;
+        // tests/tools/config2_tiles.py)
+        ba.T = (e->opt_trace_tile >= 64 && e->opt_trace_tile % 64 == 0) ? e->opt_trace_tile : 128;
         const int64_t S_total = ((int64_t)max_len + 64 + 63) / 64 * 64;
         const int64_t D = (S_total + (int64_t)(ba.W_max - 1) * (ba.T + 64) + ba.T - 1) / ba.T;
         const int64_t bblocks = (couples * ba.W_max + 3) / 4;
