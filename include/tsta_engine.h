@@ -173,7 +173,9 @@ int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
  * launch per tile diagonal, 1 single launch with tiles through memory, 2 LDS-linked quads, 3 / 4 solver bands + emitter tiles
  * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form); "last_sub_batches" = how many sub-batches the last
  * host-pointer score call was cut into (option "psa_overlap"); "psa_redo_pairs" = pairs of the last score call whose scores left
- * the packed kernel's 16-bit window and were scored by the int32 kernel instead (option "psa_f16max"; synchronises the device).
+ * the packed kernel's 16-bit window and were scored by the int32 kernel instead (option "psa_f16max"; synchronises the device);
+ * "poa_last_spread" = largest distance between two predecessor rows of one node the last POA fill saw, "poa_last_ref_w" = the -W
+ * at which the last POA fill ran in the reference's own arithmetic (0: the plain kernels served it).
  * TSTA_ERR_INVALID_ARG for an unknown key. */
 int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);
 
@@ -238,8 +240,11 @@ void tsta_alignments_free(tsta_alignment* out, int64_t n_pairs);
  *       (measured: 17 of 40 N-containing inputs gave 2-5 different outputs over -W 3/5/10/16/30);
  *   (2) the sequence spans more L-blocks than the graph, ceil(n/L) > ceil(n_nodes/L): the first-column branch at
  *       c-t-simd.c:194 lacks the guard of :263 (L = option "poa_ref_block");
- *   (3) two predecessor rows of one node lie further apart than the reference's saturating offset tracker can
- *       represent (c-t-simd.c:196-261,370-404: 100+127+127; checked conservatively on the device);
+ *   (3) two predecessor rows of one node lie further apart than the reference's int8 offsets hold exactly: an offset enters a block
+ *       clipped at 100 (c-t-simd.c:203-222), and although such a predecessor is cut off from the maximum (v > 60), its clipped
+ *       offset still feeds the F / E flags of the cell; measured on the device (largest distance between two predecessor rows of a
+ *       node), limit 100 minus what one row can add (max(|M|,|X|) + |O| + |E|) — a 90-node jump edge in a 7 x 300 bp family at
+ *       30 % divergence (spread 179) changes 19 fsource bytes at the default scoring: tests/golden/msa_spread_golden.json;
  *   (4) the last block is padded and W max(|E|, M) + |O| >= 60: one byte lane's W padding columns ('N', readseq) shift a row beyond
  *       the trackers' cutoff between the two passes (measured: -W 32 at the default scoring; the bound is empirical).
  *   (5) the SCORING lies outside M >= 1, X < M, E <= -1, O <= 0, W max(|E|, M) + |O| + |X| < 64 (W = "poa_ref_block" / 64): W columns

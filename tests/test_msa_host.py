@@ -323,3 +323,44 @@ def test_msa_domain_cli_on_gpu(tmp_path, idx):
     assert r.returncode == 0, r.stderr[-500:]
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["md5"], (c["W"], sc)
     assert r.stderr.decode().count("warning:") == 0
+
+
+# ---- predecessor rows further apart than the reference's int8 offsets hold exactly (round 4) -----------------------------------------
+# tests/golden/msa_spread_golden.json: inputs found by random campaigns on which the reference's fsource bytes are not the plain DP's
+# at the default scoring / -W (a clipped offset of a cut-off predecessor still feeds the F flags).  The int8 restatement reproduces
+# them; the engine notices the spread at run time (limit 100 - what one row can add) and runs such fills in that arithmetic.
+from tests.golden.make_msa_spread_golden import spread_case_seqs  # noqa: E402
+
+with open(os.path.join(util.GOLDEN_DIR, "msa_spread_golden.json")) as _f:
+    S_GOLDEN = json.load(_f)
+
+
+@pytest.mark.parametrize("idx", range(len(S_GOLDEN)))
+def test_msa_spread_int8_restatement_equals_the_reference(oracle_driver, tmp_path, idx):
+    c = S_GOLDEN[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    seqs = spread_case_seqs(c)
+    assert [len(s) for s in seqs] == c["lengths"]
+    write_multi_fasta(fa, seqs)
+    sc = c["scoring"]
+    assert _run_blocked(oracle_driver, fa, out, sc, -c["W"]) == c["md5"]
+    if idx == 0:                                                 # ... and the plain DP really prints something else there
+        r = subprocess.run([oracle_driver, str(sc["M"]), str(sc["X"]), str(sc["E"]), str(sc["O"]), fa, out], capture_output=True, timeout=600)
+        assert r.returncode == 0 and hashlib.md5(open(out, "rb").read()).hexdigest() != c["md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(S_GOLDEN)))
+def test_msa_spread_cli_on_gpu(tmp_path, idx):
+    c = S_GOLDEN[idx]
+    fa, out = str(tmp_path / "in.fa"), str(tmp_path / "out.txt")
+    write_multi_fasta(fa, spread_case_seqs(c))
+    sc = c["scoring"]
+    env = dict(os.environ, TSTA_MSA_SPREAD="1")
+    r = subprocess.run([os.path.join(BIN, "TSTA_msa"), "-M", str(sc["M"]), "-X", str(sc["X"]), "-E", str(sc["E"]), "-O", str(sc["O"]),
+                        "-T", "4", "-W", str(c["W"]), "-i", fa, "-o", out], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["md5"], (c["kind"], c["W"], sc)
+    assert r.stderr.decode().count("warning:") == 0
+    if idx == 0:                                                 # the steps with the jump edge ran in the reference's arithmetic
+        assert "reference arithmetic (K4e)" in r.stderr.decode()

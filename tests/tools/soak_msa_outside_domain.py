@@ -19,6 +19,14 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     w = int(rng.choice([10, 10, 10, 1, 2, 3, 5, 7, 16, 24, 30, 32]))
     seqs = [np.array(s) for s in family(int(rng.integers(1 << 30)), n_seq, length, rate)]
     kind = trial % 3
+    if len(sys.argv) > 3 and sys.argv[3] == "scoring":
+        # round 4: random SCORINGS on both sides of the routing rule (tsta_poa_reference_exact), 'N'-free equal-length or ragged
+        # families: the drop-in must print the reference's bytes wherever the reference survives its own arithmetic
+        sc = (int(rng.integers(1, 13)), 0, int(rng.integers(-10, 0)), int(rng.integers(-40, 1)))
+        sc = (sc[0], int(rng.integers(-40, sc[0])), sc[2], sc[3])
+        length = 64 * w * int(rng.integers(1, 3)) if trial % 2 else length
+        seqs = [np.array(s) for s in family(int(rng.integers(1 << 30)), n_seq, min(length, 3000), rate, jitter=trial % 2 == 0)]
+        kind = 3
     if kind in (0, 2):                                            # literal N's, anywhere
         for _ in range(int(rng.integers(1, 8))):
             k = int(rng.integers(0, n_seq)); seqs[k][int(rng.integers(0, len(seqs[k])))] = ord("N")
@@ -40,6 +48,6 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     m2 = hashlib.md5(open("/tmp/ref.txt", "rb").read()).hexdigest()
     same = a.returncode == 0 and m1 == m2 and a.stdout == b.stdout
     done += 1; bad += (not same); warned += (b"warning:" in a.stderr)
-    print("trial", trial, ["N", "ragged", "N+ragged"][kind], (n_seq, [len(s) for s in seqs], rate, sc, "W=%d" % w),
+    print("trial", trial, ["N", "ragged", "N+ragged", "scoring"][kind], (n_seq, [len(s) for s in seqs], rate, sc, "W=%d" % w),
           "MATCH" if same else "DIFFER rc=%d %s" % (a.returncode, a.stderr.decode()[-200:]), "(warned)" if b"warning:" in a.stderr else "", flush=True)
 print("compared:", done, "mismatches:", bad, "runs with a warning (fell back to the plain DP):", warned)

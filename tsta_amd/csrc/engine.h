@@ -39,6 +39,7 @@ struct Engine {
     int       last_trace_form = 0;    // how the last trace fill ran: 0 launch per tile diagonal, 1 single launch (tiles through memory), 2 LDS-linked quads,
                                       // 3 / 4 solver bands + emitter tiles (generic / pure-ACGT table), 5 coupled pairs in dataflow form
     const uint8_t* last_redo = nullptr; int64_t last_redo_n = 0;   // redo flags of the last score call (psa_score_packed.hip: F3), for tsta_engine_stat
+    int       last_poa_spread = 0;    // largest distance between two predecessor rows of one node the last plain POA fill saw
     int       last_sub_batches = 1;   // sub-batches the last host-pointer score call was cut into (overlapped upload)
     int align_calls = 0;   // tsta_psa_align_batch calls so far (its workspace cap grows with them)
 

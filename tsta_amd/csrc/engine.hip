@@ -309,6 +309,8 @@ int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
     if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
     if (!strcmp(key, "last_trace_form")) { *value = e->last_trace_form; return TSTA_OK; }
     if (!strcmp(key, "last_sub_batches")) { *value = e->last_sub_batches; return TSTA_OK; }
+    if (!strcmp(key, "poa_last_spread")) { *value = e->last_poa_spread; return TSTA_OK; }
+    if (!strcmp(key, "poa_last_ref_w")) { *value = e->poa_blocked_w; return TSTA_OK; }
     if (!strcmp(key, "psa_redo_pairs")) {               // pairs of the last score call the packed kernels handed to the int32 kernel (synchronises)
         *value = 0;
         if (!e->last_redo || e->last_redo_n <= 0 || !e->pair_flags.p) return TSTA_OK;

@@ -845,10 +845,16 @@ static bool poa_needs_reference_arithmetic(const Engine* e, const tsta_params* p
 static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const uint8_t* seq, int32_t n, int spread)
 {
     e->warn[0] = 0;
+    e->last_poa_spread = spread;                               // tsta_engine_stat("poa_last_spread")
     if (e->poa_blocked_w > 0) return TSTA_OK;
     const int64_t L = e->opt_poa_ref_block;
     const int m = std::max(std::abs(p->M), std::abs(p->X)) + std::abs(p->O) + std::abs(p->E);
-    const int limit = std::max(64, 354 - 2 * m);            // tracker range 100+127+127 (c-t-simd.c:196-261) minus what one row can add
+    // The reference's offset v_j = H(r, c-1) - H(p_j, c-1) is exact only as an int8 that enters a block at <= 100 (split_offset,
+    // c-t-simd.c:203-222: the rest goes into the reservoirs) — and although a predecessor that far below is cut off from the maximum
+    // (v_j > 60), its CLIPPED v_j still feeds the F / E flags of the cell (fv_j == O+E, :521-522,564-565).  v_j <= spread + what one row
+    // can add, so the fill is the plain DP while spread + m <= 100.  (Round 3 used the trackers' total range 354 - 2m here; a random
+    // family with a 90-node jump edge — spread 179 — showed fsource bytes of the reference that are not the DP's: round 4.)
+    const int limit = std::max(0, 100 - m);
     const void* nptr = memchr(seq, 'N', (size_t)n);
     if (nptr)
         snprintf(e->warn, sizeof(e->warn), "the sequence contains a literal 'N' (first at position %lld): the reference applies its N-column rule "
@@ -858,8 +864,8 @@ static int poa_reference_warning(Engine* e, const tsta_params* p, int V, const u
         snprintf(e->warn, sizeof(e->warn), "the sequence (%d) spans more blocks of L=%lld than the graph (%d nodes): the reference's first-column "
                  "branch (c-t-simd.c:194, unguarded unlike :263) makes its own output depend on -W here", n, (long long)L, V);
     else if (spread > limit)
-        snprintf(e->warn, sizeof(e->warn), "two predecessor rows of one node lie %d apart (limit %d): beyond the reference's saturating offset "
-                 "tracker (c-t-simd.c:196-261,370-404), its own output may deviate from the DP computed here", spread, limit);
+        snprintf(e->warn, sizeof(e->warn), "two predecessor rows of one node lie %d apart (limit %d): beyond what the reference's int8 offsets "
+                 "hold exactly (c-t-simd.c:196-261,370-404), its own output may deviate from the DP computed here", spread, limit);
     else if (char why[256]; !poa_scoring_is_plain_dp(p, L, why, sizeof(why)))
         snprintf(e->warn, sizeof(e->warn), "scoring outside the domain where the reference's POA fill is the plain DP (%s): its own output there is a "
                  "property of its int8 arithmetic and of -W; this result is the plain DP", why);

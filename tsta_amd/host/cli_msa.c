@@ -80,6 +80,12 @@ static int gpu_path(void* vctx, int n_nodes, const int32_t* pred_off, const int3
     const double t0 = now_s();
     rc = tsta_poa_align(c->eng, &c->prm, &dag, seq, n, &st, n_steps, end_col, NULL);
     c->gpu_s += now_s() - t0;
+    if (getenv("TSTA_MSA_SPREAD")) {                /* diagnostics: how far apart the predecessor rows lay, which path served the step */
+        int64_t sp = 0, rw = 0;
+        tsta_engine_stat(c->eng, "poa_last_spread", &sp); tsta_engine_stat(c->eng, "poa_last_ref_w", &rw);
+        fprintf(stderr, "[tsta] step: %d nodes x %d columns, predecessor spread %lld, %s\n", n_nodes, n, (long long)sp,
+                rw > 0 ? "reference arithmetic (K4e)" : "plain kernels");
+    }
     rc = absorb_warning(c, rc);
     if (rc != TSTA_OK) fprintf(stderr, "tsta_poa_align: %s: %s\n", tsta_strerror(rc), tsta_last_error(c->eng));
     *steps = (pg_step*)st;
