@@ -18,6 +18,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     prm = tsta_amd.Params(M, X, E, O)
     if trial % 3 == 0:                                     # literal N in the sequence (K4's segment-by-segment path)
         seq = seq.copy(); seq[rng.integers(0, len(seq), size=max(1, len(seq) // 40))] = ord("N")
+    # the plain kernels against the plain DP: routing to the reference's arithmetic off (random DAGs spread their predecessor rows far
+    # beyond what it holds exactly, some scorings lie outside its rule: round 4 sends those through K4e, checked in the second leg)
+    eng.set_option("poa_ref_arith", 0)
     for cols, dataflow in ((2, 1), (2, 0), (4, 0)):        # K4d (solver + emitters), K4 with 2 / 4 columns per lane
         eng.set_option("poa_cols", cols); eng.set_option("poa_dataflow", dataflow)
         got = eng.poa_fill(pred_off, pred, base, is_sink, seq, prm)
@@ -30,4 +33,18 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
             bad += 1
             print("MISMATCH", trial, (M, X, E, O), (V, mp, n), (cols, dataflow), flush=True)
     eng.set_option("poa_cols", 0); eng.set_option("poa_dataflow", 1)
+    # K4e (every fill in the reference's own arithmetic) against the int8 restatement, at -W 10 and another -W
+    if M >= 1 and X < M and E <= -1 and int(np.diff(pred_off).max()) <= 8:
+        eng.set_option("poa_ref_arith", 2)
+        for w in (10, int(rng.choice([3, 5, 16]))):
+            eng.set_option("poa_ref_block", 64 * w)
+            got = eng.poa_fill(pred_off, pred, base, is_sink, seq, prm)
+            if eng.last_status != 0:
+                continue                                    # (the path could not run: LDS)
+            want = util.oracle_poa_fill_i8(pred_off, pred, base, is_sink, seq, w, M=M, X=X, E=E, O=O)
+            if not (got[0] == want[0] and all(np.array_equal(g, x) for g, x in zip(got[1:], want[1:]))):
+                bad += 1
+                print("MISMATCH (reference arithmetic)", trial, (M, X, E, O), (V, mp, n), "W", w, flush=True)
+        eng.set_option("poa_ref_block", 640)
+    eng.set_option("poa_ref_arith", 1)
 print("mismatches:", bad, "%.0f s" % (time.time() - t0))
