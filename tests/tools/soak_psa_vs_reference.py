@@ -41,6 +41,13 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
         elif k7 == 4: b = a.copy()
         else: a = np.full(n, ord("A"), np.uint8); b = np.full(m, ord("A"), np.uint8)
         if len(b) == 0: b = a[:1]
+        if len(sys.argv) > 4 and sys.argv[4] == "alphabet":      # bytes that are not ACGT: PSA compares them as they are (psa.c:248-259)
+            def sprinkle(x):
+                x = x.copy()
+                hit = rng.random(len(x)) < 0.03
+                x[hit] = rng.choice(np.frombuffer(b"NnacgtRYKMSW*-", dtype=np.uint8), int(hit.sum()))
+                return x
+            a = sprinkle(a); b = sprinkle(b)
     fasta("/tmp/sa.fa", b"a", a); fasta("/tmp/sb.fa", b"b", b)
     args = ["-M", str(sc[0]), "-X", str(sc[1]), "-E", str(sc[2]), "-O", str(sc[3]), "-1", "/tmp/sa.fa", "-2", "/tmp/sb.fa"]
     x = subprocess.run([os.path.join(ROOT, "tsta_amd/bin/TSTA_psa")] + args + ["-o", "/tmp/ours.txt"], capture_output=True)
