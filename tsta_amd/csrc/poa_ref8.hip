@@ -101,10 +101,11 @@ __device__ __forceinline__ int wave_sum(int x) { return __builtin_amdgcn_readlan
 // non-zero is run again with the full tracker.
 __device__ __forceinline__ void tracker_step_empty(int best, int t, int& v, int& spill)
 {
-    int d = subs8(best, t);
+    const int d = subs8(best, t);
     const int vc0 = adds8(v, d);
-    d = max(d, 0);
-    spill |= subus8(d, subs8(127, v));
+    // y = subus8(max(d, 0), subs8(127, v)) is non-zero exactly when v + d exceeds 127, i.e. when the add above saturated upwards; any
+    // saturation of it (either side) sends the row to the general sweeps
+    spill |= (v + d) ^ vc0;
     v = vc0;
 }
 
@@ -357,20 +358,33 @@ __global__ __launch_bounds__(64) void poa_ref8_kernel(PoaRef8Args P)
         pending_pub = false;
     };
 
+    // the row's graph metadata is fetched one row ahead (scalar loads whose latency a lone wave would otherwise wait out at every row's
+    // start); the row block advances by counting instead of dividing
+    const int n_pred_total = A.pred_off[V];
+    int po_cur = A.pred_off[0], po_next = A.pred_off[V > 0 ? 1 : 0], base_next = V > 0 ? A.base[0] : 0;
+    int p0_next = (po_cur < po_next) ? A.pred[po_cur] : V;
+    int rb = 0, r_in_blk = 0;
     for (int r = 0; r < V; ++r) {
-        const int poff = A.pred_off[r];
-        int np = A.pred_off[r + 1] - poff;
+        const int poff = po_cur;
+        int np = po_next - poff;
         const bool is_src = (np == 0);
         if (is_src) np = 1;
-        const int base = A.base[r];
+        const int base = base_next;
+        const int pj0 = is_src ? V : p0_next;
+        if (r + 1 < V) {                               // next row's: issued now, consumed at the top of the next iteration
+            po_cur = po_next;
+            po_next = A.pred_off[r + 2];
+            base_next = A.base[r + 1];
+            p0_next = po_cur < n_pred_total ? A.pred[po_cur] : V;       // (the first predecessor, if the row has one)
+        }
         // where control() runs this (row block, column block) pair: task (block_i, block_j, block_l) (:1020-1044, :611-638)
-        const int rb = r / L, bi = rb + k;
+        const int rb_row = rb, bi = rb_row + k;         // rb_row = r / L
+        if (++r_in_blk == L) { r_in_blk = 0; ++rb; }
         const int bj = bi <= P.fmaxtag ? bi + 1 : (bi <= P.lmaxtag ? P.fmaxtag + 1 : P.fmaxtag + 1 - (bi - P.lmaxtag));
-        const int bl = rb - max(bi - P.maxtag, 0);
+        const int bl = rb_row - max(bi - P.maxtag, 0);
         const bool first_task = bi <= P.lmaxtag && bl == bj - 1;          // :194
         const bool f0_init = first_task && bi < P.nrowblk;                // :263
 
-        const int pj0 = is_src ? V : A.pred[poff];
         const bool one_fast = fastW && np == 1;
         const bool multi_fast = fastW && (np == 2 || np == 3);   // row_multi_fast<10, np>
         const bool from_prev = one_fast && !is_src && pj0 == prev_r;
