@@ -96,6 +96,12 @@ int  tsta_engine_release_workspaces(tsta_engine* eng);
  *                      bytes: only what the next step needs is on the chain of dependent steps) and computes the trace bytes in
  *                      independent EMITTER tiles that restart from checkpoints the solvers leave (psa_trace_split_kernel) | 0: never |
  *                      2: at any size (tests)
+ *   "walk_table"       1 (default): the traceback walk of ONE pair with >= 192 bands of 128 rows crosses its bands through a
+ *                      table computed for all entry columns of a corridor at once (psa_trace.hip, K3t; a band whose entry is not in
+ *                      the table is walked step by step as before: the ops are the same either way) | 0: never | 2: from one band up (tests)
+ *   "walk_corridor"    512 (default) | multiple of 256: width in columns of that corridor, centred on the straight line between
+ *                      the corners of the matrix (the table's cost grows with it: 0.3 / 0.55 / 1.5 ms at 256 / 512 / 1024 on a
+ *                      100 kbp pair)
  *   "poa_dataflow"     1 (default): POA fill as one launch, one workgroup per 128-column chunk with a solver wave, five emitter
  *                      waves and a fetcher wave (poa_dataflow.hip; sequences without 'N').  Roles are tickets drawn in start
  *                      order, so a workgroup only waits for one that is already running; should a launch abandon its (bounded)
@@ -174,7 +180,8 @@ int tsta_psa_score_batch_dev_status(tsta_engine* eng, void* stream);
  * with the generic / pure-ACGT step, 5 coupled pairs in dataflow form); "last_sub_batches" = how many sub-batches the last
  * host-pointer score call was cut into (option "psa_overlap"); "psa_redo_pairs" = pairs of the last score call whose scores left
  * the packed kernel's 16-bit window and were scored by the int32 kernel instead (option "psa_f16max"; synchronises the device);
- * "poa_last_spread" = largest distance between two predecessor rows of one node the last POA fill saw, "poa_last_ref_w" = the -W
+ * "last_walk_jumps" = bands the last single-pair
+ * walk crossed by table look-up; "poa_last_spread" = largest distance between two predecessor rows of one node the last POA fill saw, "poa_last_ref_w" = the -W
  * at which the last POA fill ran in the reference's own arithmetic (0: the plain kernels served it).
  * TSTA_ERR_INVALID_ARG for an unknown key. */
 int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value);

@@ -329,3 +329,62 @@ def test_batch_packed_trace_fill(eng, scoring):
     finally:
         eng.set_option("trace_rows", 0); eng.set_option("trace_packed", 1); eng.set_option("trace_tile", 0)
         eng.set_option("psa_elide", 1); eng.set_option("psa_perm", 1)
+
+
+def _structured_pair(seed, n, rate, big_del=0, big_ins=0):
+    """a pair whose path drifts off the end-anchored diagonal: point mutations + one long deletion / insertion in the middle"""
+    a = util.random_dna(seed, n)
+    b = util.mutate(a, seed + 1, rate)
+    mid = len(b) // 2
+    if big_del:
+        b = np.concatenate([b[:mid], b[mid + big_del:]])
+    if big_ins:
+        b = np.concatenate([b[:mid], util.random_dna(seed + 2, big_ins), b[mid:]])
+    return a, b
+
+
+@pytest.mark.parametrize("scoring", [dict(M=2, X=-5, E=-2, O=-4), dict(M=1, X=-1, E=-1, O=0), dict(M=10, X=-10, E=-3, O=-12)])
+def test_walk_through_the_band_table_equals_the_step_walk(eng, scoring):
+    """K3t (psa_trace.hip): the single-pair walk crossing its bands by table look-up emits the ops of the step-by-step walk, whatever part
+    of the path the corridor covers: narrow corridors, long indels that carry the path out of it and back, both orientations."""
+    p = tsta_amd.Params(**scoring)
+    cases = [_structured_pair(9100, 3000, 0.08), _structured_pair(9110, 6000, 0.15), _structured_pair(9120, 5000, 0.05, big_del=700),
+             _structured_pair(9130, 5000, 0.05, big_ins=900), _structured_pair(9140, 9000, 0.10, big_del=300, big_ins=300),
+             (util.random_dna(9150, 2500), util.random_dna(9151, 4100)), (util.low_complexity(9160, 4000), util.low_complexity(9161, 3800))]
+    try:
+        for a, b in cases:
+            for x, y in ((a, b), (b, a)):
+                eng.set_option("walk_table", 0)
+                want = eng.psa_align(x, y, p)
+                assert eng.stat("last_walk_jumps") == 0
+                for corridor in (256, 1024):
+                    eng.set_option("walk_table", 2); eng.set_option("walk_corridor", corridor)
+                    got = eng.psa_align(x, y, p)
+                    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+                    if min(len(x), len(y)) >= 2048 and corridor == 1024:
+                        assert eng.stat("last_walk_jumps") > 0            # (the table is really in use)
+        a, b = cases[1]
+        eng.set_option("walk_table", 2); eng.set_option("walk_corridor", 1024)
+        ms, ra, rb = eng.psa_align(a, b, p)
+        o_ms, _, o_ra, o_rb = util.oracle_align(a, b, **scoring)
+        assert (ms, ra, rb) == (o_ms, o_ra, o_rb)
+    finally:
+        eng.set_option("walk_table", 1); eng.set_option("walk_corridor", 1024)
+
+
+def test_walk_table_is_the_default_on_the_100k_pair(eng):
+    """config #3: nearly every band of the 100 kbp pair is crossed by look-up; the output is the reference's file either way
+    (test_full_size_100k_md5_matches_reference runs with the default options)"""
+    import json
+    g = json.load(open(os.path.join(util.GOLDEN_DIR, "psa_big_golden.json")))
+    x = util.random_dna(g["seed_x"], g["len_x"]); y = util.mutate(x, g["seed_y"], g["rate"])
+    ms, ra, rb = eng.psa_align(x, y)
+    jumps = eng.stat("last_walk_jumps")
+    nb = (len(y) - 1) // 128
+    assert jumps >= 0.9 * nb, (jumps, nb)          # (all but the bands entered in the middle of a vertical gap)
+    try:
+        eng.set_option("walk_table", 0)
+        ms0, ra0, rb0 = eng.psa_align(x, y)
+    finally:
+        eng.set_option("walk_table", 1)
+    assert (ms, ra, rb) == (ms0, ra0, rb0)

@@ -28,7 +28,7 @@ struct Engine {
     char        warn[512] = {0};   // text behind the last TSTA_WARN_* status
 
     // tuning knobs (tsta_engine_set_option); defaults may be preset by the TSTA_* environment variables
-    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1, opt_psa_overlap = 1, opt_psa_f16max = 1;
+    int opt_psa_packed = -1, opt_psa_rows = 0, opt_trace_rows = 0, opt_trace_tile = 0, opt_poa_cols = 0, opt_psa_elide = 1, opt_psa_perm = 1, opt_trace_packed = 1, opt_trace_streams = 0, opt_psa_bands = -1, opt_trace_persistent = 1, opt_psa_ffree = 1, opt_poa_ref_block = 640, opt_align_ws_gb = 0, opt_poa_dataflow = 1, opt_trace_lds = 1, opt_test_abandon = 0, opt_trace_split = 1, opt_poa_n_blocked = 1, opt_psa_overlap = 1, opt_psa_f16max = 1, opt_walk_corridor = 512, opt_walk_table = 1;
     unsigned* psa_status = nullptr;   // device word the last tsta_psa_score_batch_dev's single-launch band pipeline (K1b) reports into, or null
     bool      no_single_launch = false;   // set around such a second run
     int       single_launch_reruns = 0;   // calls that were run again through the launch pipeline after an abandoned single launch
@@ -57,6 +57,8 @@ struct Engine {
     hipEvent_t ev_tab = nullptr; // ... which this event marks the end of (waited for before the table is rewritten)
     DevBuf pair_flags;   // per-pair alphabet flags of the packed score kernel
     DevBuf ckpt;         // single-pair trace fill, split form: lane-state checkpoints the emitter tiles start from
+    DevBuf walk_tab;     // single-pair traceback: band-crossing table of the walk + the segments it jumped (psa_trace.hip, K3t)
+    int    last_walk_jumps = 0;   // bands the last single-pair walk crossed through the table
 
     void set_error(const char* fmt, ...);
     int  check(hipError_t e, const char* what);

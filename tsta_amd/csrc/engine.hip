@@ -241,7 +241,7 @@ void tsta_engine_destroy(tsta_engine* eng)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (tsta::DevBuf* b : {&e->counter, &e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch,
-                            &e->scratch2, &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
+                            &e->scratch2, &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt, &e->walk_tab}) {
         if (b->p) (void)hipFree(b->p);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -265,7 +265,7 @@ int tsta_engine_release_workspaces(tsta_engine* eng)
     if ((rc = e->check(hipStreamSynchronize(e->stream), "hipStreamSynchronize")) != TSTA_OK) return rc;
     // everything but the small counter block (ticket words, self-test / result scalars)
     for (tsta::DevBuf* b : {&e->rows, &e->in_seqs, &e->in_meta, &e->out_scores, &e->trace, &e->scratch, &e->scratch2,
-                            &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt}) {
+                            &e->pair_flags, &e->unpacked, &e->unpacked2, &e->ckpt, &e->walk_tab}) {
         if (b->p) { e->forget_status_in(*b); (void)hipFree(b->p); }
         if (b == &e->pair_flags) { e->last_redo = nullptr; e->last_redo_n = 0; }
         b->p = nullptr; b->bytes = 0;
@@ -296,6 +296,8 @@ int tsta_engine_set_option(tsta_engine* eng, const char* key, int64_t value)
     if (!strcmp(key, "poa_dataflow") && (v == 0 || v == 1 || v == 2)) { e->opt_poa_dataflow = v; return TSTA_OK; }
     if ((!strcmp(key, "poa_ref_arith") || !strcmp(key, "poa_n_blocked")) && (v == 0 || v == 1 || v == 2)) { e->opt_poa_n_blocked = v; return TSTA_OK; }
     if (!strcmp(key, "trace_split") && (v == 0 || v == 1 || v == 2)) { e->opt_trace_split = v; return TSTA_OK; }
+    if (!strcmp(key, "walk_table") && v >= 0 && v <= 2) { e->opt_walk_table = v; return TSTA_OK; }
+    if (!strcmp(key, "walk_corridor") && v >= 0 && v <= 65536 && v % 256 == 0) { e->opt_walk_corridor = v; return TSTA_OK; }
     if (!strcmp(key, "test_abandon") && v >= 0) { e->opt_test_abandon = v; return TSTA_OK; }
     if (!strcmp(key, "poa_ref_block") && v >= 16 && v <= (1 << 20) && v % 16 == 0) { e->opt_poa_ref_block = v; return TSTA_OK; }
     if (!strcmp(key, "trace_tile") && v >= 0 && v % 64 == 0 && v <= 4096) { e->opt_trace_tile = v; return TSTA_OK; }
@@ -308,6 +310,7 @@ int tsta_engine_stat(const tsta_engine* eng, const char* key, int64_t* value)
     const Engine* e = reinterpret_cast<const Engine*>(eng);
     if (!strcmp(key, "single_launch_reruns")) { *value = e->single_launch_reruns; return TSTA_OK; }
     if (!strcmp(key, "last_trace_form")) { *value = e->last_trace_form; return TSTA_OK; }
+    if (!strcmp(key, "last_walk_jumps")) { *value = e->last_walk_jumps; return TSTA_OK; }
     if (!strcmp(key, "last_sub_batches")) { *value = e->last_sub_batches; return TSTA_OK; }
     if (!strcmp(key, "poa_last_spread")) { *value = e->last_poa_spread; return TSTA_OK; }
     if (!strcmp(key, "poa_last_ref_w")) { *value = e->poa_blocked_w; return TSTA_OK; }

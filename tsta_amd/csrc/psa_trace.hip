@@ -366,6 +366,24 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
     quad_band<R, false>(A, __builtin_amdgcn_readfirstlane(wg_s), wave, lane, ring, done);
 }
 
+// emitter tiles of the split form are numbered along the diagonals u = w + c K (tile (band w, chunk c) becomes available ~when the
+// tiles of diagonal u do): diag_first[u] = number of tiles on the diagonals before u, diag_first[n_diag] = all of them
+__global__ __launch_bounds__(256) void psa_split_diag_kernel(int* diag_first, int n_diag, int W, int NC, int K)
+{
+    __shared__ int part[257];
+    auto count = [&](int u) { const int c_lo = max(0, (u - (W - 1) + K - 1) / K), c_hi = min(NC - 1, u / K); return max(0, c_hi - c_lo + 1); };
+    const int per = (n_diag + 255) / 256, u0 = (int)threadIdx.x * per, u1 = min(n_diag, u0 + per);
+    int sum = 0;
+    for (int u = u0; u < u1; ++u) sum += count(u);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = acc; acc += v; } part[256] = acc; }
+    __syncthreads();
+    int acc = part[threadIdx.x];
+    for (int u = u0; u < u1; ++u) { diag_first[u] = acc; acc += count(u); }
+    if (threadIdx.x == 0) diag_first[n_diag] = part[256];
+}
+
 // ---- split form: solvers on the chain, emitters beside it ----------------------------------------------------------------
 // The chain of dependent steps of ONE pair is what its fill costs (n + bands x ~100 steps, one wave per band, a lone wave
 // issuing one VALU instruction every ~5.2 cycles): the fewer instructions a step has, the shorter the fill.  Of the ~56
@@ -582,14 +600,21 @@ __global__ void psa_trace_finish_kernel(const TraceJob* jobs)
     const int* state = J.state;
     const int W = J.W, m = J.m;
     int mx = kNegInfT;
-    for (int idx = threadIdx.x; idx < W * 64; idx += blockDim.x) {
-        const int w = idx / 64, lane = idx % 64;
-        mx = max(mx, state[(size_t)w * NS * 64 + (2 * R + 4) * 64 + lane]);
+    // (1 024 threads, four independent loads in flight per thread: a long pair has ~50 000 lane maxima, and a loop of dependent
+    // round trips over them was 77 us of a 100 kbp alignment)
+    const int total = W * 64, stride = (int)blockDim.x;
+    int idx = threadIdx.x;
+    for (; idx + 3 * stride < total; idx += 4 * stride) {
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int x = idx + q * stride; v[q] = state[(size_t)(x / 64) * NS * 64 + (2 * R + 4) * 64 + x % 64]; }
+        mx = max(max(mx, max(v[0], v[1])), max(v[2], v[3]));
     }
-    __shared__ int red[256];
+    for (; idx < total; idx += stride) mx = max(mx, state[(size_t)(idx / 64) * NS * 64 + (2 * R + 4) * 64 + idx % 64]);
+    __shared__ int red[1024];
     red[threadIdx.x] = mx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    for (int o = (int)blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
     if (threadIdx.x == 0) {
         J.out[0] = max(red[0], -100);
         const int rr = (m - 1) % (64 * R), w = (m - 1) / (64 * R);
@@ -614,8 +639,125 @@ __device__ __forceinline__ uint4 ld_global_u4(GlobalConstU4* p) { const u32x4_t 
 typedef __attribute__((address_space(1))) const uint8_t GlobalConstU8;
 typedef __attribute__((address_space(1))) uint8_t GlobalU8;
 
-template <int R, int NQ>
-__global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
+// ---- K3t (round 4): the walk of ONE long pair crosses its bands through a table ----------------------------------------------
+// The walk is one wave following a chain of dependent steps (~30 ns per step, ~1.2 us per band crossed: 3.1 ms on a 100 kbp pair).
+// But the part of it inside one band depends only on where, and in which state, it enters the band: from (i = b BAND, j, forced)
+// to the first moment i = (b-1) BAND.  psa_walk_origin_kernel computes that for EVERY entry column of a corridor around the
+// straight line between the matrix's corners (the walk is pinned at both), every band boundary and the free entry state
+// (forced = -1; a band entered in the middle of a vertical gap, forced = 2, is rare — about one in a hundred — and walked step by
+// step), one thread per entry, all of them at once: table entry = {columns moved, ops emitted, state at the exit}.  The walker then
+// crosses a band with one table look-up (slices of 32 boundaries staged in LDS at a time, around the diagonal through the current
+// cell), noting where it entered; psa_walk_emit_kernel walks every noted band again, one thread per band, and writes its ops at the
+// offset the walker counted.  Exactness does not depend on the table: an entry that is missing (outside the corridor, a walk
+// that ends inside the band or wanders for more than 1 000 steps) is simply a band the walker crosses step by step as before.
+struct WalkTabArgs {
+    unsigned* tab;       // [nb + 1][Wc]: boundary b = 1 .. nb (row i = b BAND), entry column lo(b) + idx, entered free (forced = -1); null: no table
+    int Wc, nb;          // corridor width in columns (multiple of 256), boundaries
+    int* lo;             // [nb + 1]: first column of boundary b's corridor (written by psa_walk_origin_kernel)
+    int* seg;            // [2 (nb + 1)]: seg[2b] = entry column of a band crossed by look-up (0: not), seg[2b+1] = ops before it
+};
+// entry: bits 0-9 ops emitted, 10-19 columns moved, 20 forced == 2 at the exit, 31 valid
+
+__device__ __forceinline__ int corridor_lo(int b, int band, int n, int m, int Wc)
+{
+    const int c = (int)((long long)n * (b * band) / m);      // the straight line from (m, n) to (0, 0) at row b BAND: the walk is pinned at both ends
+    return max(1, min(c - Wc / 2, n - Wc + 1));
+}
+
+// trace byte of the 1-based cell (ci, cj), per lane, from memory (unsigned arithmetic: shifts, no sign fix-ups; the offset inside a
+// band fits 32 bits; a global, not a flat, load)
+template <int R>
+__device__ __forceinline__ unsigned trace_byte_at(const uint8_t* __restrict__ trace, int64_t band_bytes, int ci, int cj)
+{
+    constexpr unsigned SPB = TraceCfg<R>::SPB, BAND = 64 * R;
+    const unsigned u = (unsigned)(ci - 1);
+    const unsigned cw = u / BAND, rr = u % BAND, cl = rr / R, ck = rr % R;
+    const unsigned ct = (unsigned)(cj - 1) + cl;
+    const unsigned off = ((ct / SPB) * 64u + cl) * 16u + (ct % SPB) * R + ck;
+    typedef __attribute__((address_space(1))) const uint8_t GlobalByte;
+    return *(GlobalByte*)(trace + (size_t)cw * (size_t)band_bytes + off);
+}
+
+// one step of the walk (psa.c:441-463, as psa_walk_kernel below takes it), per lane; `byte(ci, cj)` = trace byte of a cell; returns the op
+template <class Fetch>
+__device__ __forceinline__ int walk_one_step(Fetch&& byte, int& i, int& j, int& forced)
+{
+    int k;
+    if (forced >= 0) { k = forced; forced = -1; }
+    else { const unsigned c = byte(i, j); k = !(c & 1u) ? 1 : (!(c & 2u) ? 0 : 2); }
+    if (k != 1) {
+        // a gap step: continue it if it was an extension, or it was opened and the next cell in its direction is "opened & tied"
+        // (left: F bits of (i, j-1), (i, j-2); up: E bits of (i-1, j), (i-2, j)) — one code path for both directions
+        const int di = k == 2 ? 1 : 0, dj = k == 0 ? 1 : 0, sh = k == 2 ? 4 : 2;
+        const int a = k == 2 ? i - 1 : j - 1;
+        if (a >= 1) {
+            const unsigned c1 = (byte(i - di, j - dj) >> sh) & 3u;
+            bool open_n = true;
+            if (a != 1) open_n = ((byte(i - 2 * di, j - 2 * dj) >> sh) & 3u) >= 1u;
+            if (c1 < 1u || (open_n && c1 == 1u)) forced = k;
+        }
+    }
+    i -= (k != 0) ? 1 : 0;                                   // (arithmetic, not branches: the compiler otherwise keeps {i, j} as an indexed array in scratch)
+    j -= (k != 2) ? 1 : 0;
+    return k;
+}
+
+// one thread per entry column of one boundary (the bytes come through the caches: walks of neighbouring columns share their lines;
+// staging a workgroup's region in LDS first was measured at twice the time)
+template <int R>
+__global__ __launch_bounds__(256) void psa_walk_origin_kernel(const TraceJob* jobs, WalkTabArgs T)
+{
+    constexpr int BAND = 64 * R;
+    const TraceJob& J = jobs[0];
+    const int b = (int)blockIdx.y + 1;
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= T.Wc) return;
+    const int n = J.n, m = J.m;
+    const int lo = corridor_lo(b, BAND, n, m, T.Wc);
+    if (idx == 0) T.lo[b] = lo;                              // (for the walker: one 64-bit division per boundary, here)
+    const int j0 = lo + idx;
+    unsigned out = 0u;
+    if (j0 <= n) {
+        int i = b * BAND, j = j0, forced = -1, cnt = 0;
+        const int stop = i - BAND;
+        bool ok = true;
+        const uint8_t* __restrict__ trace = J.trace;
+        const int64_t band_bytes = J.band_bytes;
+        auto byte = [&](int ci, int cj) -> unsigned { return trace_byte_at<R>(trace, band_bytes, ci, cj); };
+        while (i > stop) {
+            if (j < 1 || cnt >= 1000) { ok = false; break; }
+            walk_one_step(byte, i, j, forced);
+            ++cnt;
+        }
+        if (ok && j >= 1) out = (unsigned)cnt | ((unsigned)(j0 - j) << 10) | (forced == 2 ? 1u << 20 : 0u) | 0x80000000u;
+    }
+    // (a walk that enters a band in the middle of a vertical gap, forced = 2, is rare — about one band in a hundred — and not
+    // tabulated: half the table's work for nothing; the walker crosses such a band step by step)
+    T.tab[(size_t)b * T.Wc + idx] = out;
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void psa_walk_emit_kernel(const TraceJob* jobs, WalkTabArgs T)
+{
+    constexpr int BAND = 64 * R;
+    const TraceJob& J = jobs[0];
+    const int b = (int)(blockIdx.x * 64 + threadIdx.x) + 1;
+    if (b > T.nb) return;
+    const int sj = T.seg[2 * b];
+    if (sj == 0) return;
+    int i = b * BAND, j = sj, forced = -1, cnt = T.seg[2 * b + 1];
+    const int stop = i - BAND;
+    typedef __attribute__((address_space(1))) uint8_t GlobalByteW;
+    GlobalByteW* ops = (GlobalByteW*)J.ops;
+    const uint8_t* __restrict__ trace = J.trace;
+    const int64_t band_bytes = J.band_bytes;
+    auto byte = [&](int ci, int cj) -> unsigned { return trace_byte_at<R>(trace, band_bytes, ci, cj); };
+    while (i > stop && j >= 1) ops[cnt++] = (uint8_t)walk_one_step(byte, i, j, forced);
+}
+
+// TAB: with the band table of K3t (a separate instantiation: the slices in flight cost registers the plain walker does without)
+template <int R, int NQ, bool TAB>
+__global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs, WalkTabArgs T)
 {
     WalkArgs A;
     {
@@ -634,7 +776,48 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
     uint4 pre[NQ];
     int pre_w = -1, pre_qlo = 0, pre_qhi = -1;
     const int groups_per_band = (int)(A.band_bytes / (64 * 16));
+    int jumps = 0;
     while (i >= 1 && j >= 1) {
+        if constexpr (TAB && NQ == 32) if (forced < 0 && i % BAND == 0 && i / BAND >= 1 && i / BAND <= T.nb) {
+            // ---- at a band boundary, free: the slices of this and the next 31 boundaries around the diagonal through (i, j) — 256
+            // entry columns, 1 KB each — go into the window's LDS, then up to 32 bands are crossed by look-up
+            const int b0 = i / BAND;
+            const int lo_l = T.lo[max(1, b0 - (lane & 31))];               // lane k: first corridor column of boundary b0 - k
+            if ((unsigned)(j - __builtin_amdgcn_readfirstlane(lo_l)) < (unsigned)T.Wc) {
+                unsigned* tw = reinterpret_cast<unsigned*>(win);
+                int ws[32], los[32];
+                uint4 tmp[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int bb = max(1, b0 - k);
+                    los[k] = __builtin_amdgcn_readlane(lo_l, k);
+                    ws[k] = max(0, min(j - k * BAND - 128 - los[k], T.Wc - 256)) & ~3;
+                    tmp[k] = ld_global_u4((GlobalConstU4*)(T.tab + (size_t)bb * T.Wc + ws[k]) + lane);
+                }
+#pragma unroll
+                for (int k = 0; k < 32; ++k) win[k * 64 + lane] = tmp[k];
+                __syncthreads();
+                int jumped = 0;
+                bool go = true;                               // (no break: the loop unrolls, ws[] stays in registers)
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int bb = b0 - k;
+                    const int idx = j - los[k] - ws[k];
+                    go = go && forced < 0 && bb >= 1 && j >= 1 && (unsigned)idx < 256u;
+                    unsigned en = 0u;
+                    if (go) en = (unsigned)__builtin_amdgcn_readfirstlane((int)tw[k * 256 + idx]);
+                    go = go && (en >> 31) != 0u;
+                    if (go) {
+                        if (lane == 0) { T.seg[2 * bb] = j; T.seg[2 * bb + 1] = cnt; }
+                        cnt += (int)(en & 1023u); j -= (int)((en >> 10) & 1023u); forced = ((en >> 20) & 1u) ? 2 : -1; i -= BAND;
+                        ++jumped;
+                    }
+                }
+                __syncthreads();
+                jumps += jumped;
+                if (jumped) continue;
+            }
+        }
         // stage the window that ends at the current cell's step group (one band, NQ step groups of 1 KiB)
         const int w = (i - 1) / BAND;
         const int ln = ((i - 1) % BAND) / R;
@@ -768,7 +951,7 @@ __global__ __launch_bounds__(64) void psa_walk_kernel(const TraceJob* jobs)
         }
         __syncthreads();
     }
-    if (lane == 0) { A.out[2] = cnt; A.out[3] = i; A.out[4] = j; }
+    if (lane == 0) { A.out[2] = cnt; A.out[3] = i; A.out[4] = j; A.out[5] = jumps; }
 }
 
 // One oriented pair on the host side of a group, and what comes back for it.
@@ -1014,7 +1197,6 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     }
     bool quad = false;
     e->last_trace_form = persistent_couples ? 5 : persistent ? 1 : 0;      // tsta_engine_stat("last_trace_form"); refined below
-    std::vector<int> diag_tab;
     if constexpr (TRACE && R <= 2) {
         quad = persistent && !persistent_couples && e->opt_trace_lds != 0 && ((single_bands + 3) / 4 <= e->n_cu || e->opt_trace_lds == 2);
         // split form: worth it once the pair has enough bands for the chain to matter (and only while every solver workgroup
@@ -1029,18 +1211,14 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
         if (split && e->reserve(e->ckpt, ckpt_bytes + (want_clock ? (size_t)J0.W * 16 : 0) + 256, "hipMalloc(checkpoints)") == TSTA_OK) {
             if (want_clock) A.dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(e->ckpt.p) + ckpt_bytes);
             const int n_diag = (J0.W - 1) + (NC - 1) * kSplitK + 1;
-            diag_tab.assign((size_t)n_diag + 1, 0);
-            int64_t total = 0;
-            for (int u = 0; u < n_diag; ++u) {
-                const int c_lo = std::max(0, (u - (J0.W - 1) + kSplitK - 1) / kSplitK), c_hi = std::min(NC - 1, u / kSplitK);
-                diag_tab[(size_t)u] = (int)total;
-                total += std::max(0, c_hi - c_lo + 1);
-            }
-            diag_tab[(size_t)n_diag] = (int)total;
-            if (total != (int64_t)J0.W * NC || diag_tab.size() > split_tab_ints) return TSTA_ERR_INTERNAL;
+            // (the table diag_first[u] = first ticket of diagonal u is built on the device, psa_split_diag_kernel: a copy from pageable
+            // host memory here stalled the host for ~70 us between the init kernel and the fill)
+            const int64_t total = (int64_t)J0.W * NC;
+            if ((size_t)n_diag + 1 > split_tab_ints) return TSTA_ERR_INTERNAL;
             int* d_eprog = d_sync + 64 + single_bands + couple_bands;                       // cleared by the memset above
             int* d_diag = d_sync + 2 * single_bands + couple_bands + 128 + 2 * d_bound;     // behind the couples' tile table
-            if ((rc = e->check(hipMemcpyAsync(d_diag, diag_tab.data(), diag_tab.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D emitter tile table"))) return rc;
+            hipLaunchKernelGGL(psa_split_diag_kernel, dim3(1), dim3(256), 0, s, d_diag, n_diag, J0.W, NC, kSplitK);
+            ++launches;
             A.eprog = d_eprog; A.ckpt = reinterpret_cast<int*>(e->ckpt.p); A.C = kSplitC; A.NC = NC; A.K = kSplitK;
             A.n_solver_wg = (int)((single_bands + 3) / 4);
             A.tile_ticket = reinterpret_cast<unsigned*>(d_sync + 3); A.diag_first = d_diag; A.n_diag = n_diag; A.n_tiles = (int)total;
@@ -1123,9 +1301,29 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             return rc;
     }
     if (single_on_side && (rc = e->check(hipStreamWaitEvent(s, e->ev_join[0], 0), "hipStreamWaitEvent(join)"))) return rc;
-    if (n_singles) hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_singles), dim3(256), 0, s, d_singles);
+    if (n_singles) hipLaunchKernelGGL(psa_trace_finish_kernel<R>, dim3(n_singles), dim3(n_singles == 1 ? 1024 : 256), 0, s, d_singles);
     if (n_couples) launch_psa_trace_packed_finish(d_jobs, d_couples, n_couples, s);     // (does not use band0)
-    if (TRACE) hipLaunchKernelGGL((psa_walk_kernel<R, 32>), dim3(n_jobs), dim3(64), 0, s, d_jobs);
+    if constexpr (TRACE) {
+        WalkTabArgs WT; WT.tab = nullptr; WT.Wc = 0; WT.nb = 0; WT.seg = nullptr; WT.lo = nullptr;
+        // one long pair: the walk crosses its bands through a table (K3t above); worth its fixed cost (three launches, two of them bound
+        // by the latency of ~150 dependent loads) from ~200 bands up
+        const int nb = n_jobs == 1 ? (jobs[0].m - 1) / (64 * R) : 0;
+        int Wc = std::min(e->opt_walk_corridor, jobs[0].n / 256 * 256);
+        if constexpr (R == 2) if (n_jobs == 1 && Wc >= 256 && ((e->opt_walk_table == 1 && nb >= 192) || (e->opt_walk_table == 2 && nb >= 1))) {
+            const size_t tab_b = ((size_t)(nb + 1) * Wc * sizeof(unsigned) + 255) / 256 * 256, seg_b = ((size_t)2 * (nb + 1) * sizeof(int) + 255) / 256 * 256;
+            if (e->reserve(e->walk_tab, tab_b + seg_b + (size_t)(nb + 1) * sizeof(int) + 256, "hipMalloc(walk table)") == TSTA_OK) {
+                WT.tab = reinterpret_cast<unsigned*>(e->walk_tab.p); WT.Wc = Wc; WT.nb = nb;
+                WT.seg = reinterpret_cast<int*>(reinterpret_cast<char*>(e->walk_tab.p) + tab_b);
+                WT.lo = reinterpret_cast<int*>(reinterpret_cast<char*>(e->walk_tab.p) + tab_b + seg_b);
+                if ((rc = e->check(hipMemsetAsync(WT.seg, 0, seg_b, s), "hipMemsetAsync(walk segments)"))) return rc;
+                hipLaunchKernelGGL((psa_walk_origin_kernel<R>), dim3((unsigned)((Wc + 255) / 256), (unsigned)nb), dim3(256), 0, s, d_jobs, WT);
+                ++launches;
+            } else { e->err[0] = '\0'; }
+        }
+        if (WT.tab) hipLaunchKernelGGL((psa_walk_kernel<R, 32, true>), dim3(n_jobs), dim3(64), 0, s, d_jobs, WT);
+        else        hipLaunchKernelGGL((psa_walk_kernel<R, 32, false>), dim3(n_jobs), dim3(64), 0, s, d_jobs, WT);
+        if constexpr (R == 2) if (WT.tab) { hipLaunchKernelGGL((psa_walk_emit_kernel<R>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, d_jobs, WT); ++launches; }
+    }
     launches += 3;
     e->n_launches = launches;
     e->timing_end(s);
@@ -1169,6 +1367,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
     for (int j = 0; j < n_jobs; ++j) {
         jobs[j].maxscore = h_out[8 * j]; jobs[j].end_score = h_out[8 * j + 1];
         if (!TRACE) continue;
+        if (n_jobs == 1) e->last_walk_jumps = h_out[8 * j + 5];
         const int cnt = h_out[8 * j + 2]; jobs[j].fi = h_out[8 * j + 3]; jobs[j].fj = h_out[8 * j + 4];
         if (cnt < 0 || cnt > jobs[j].n + jobs[j].m) { e->set_error("walker returned %d ops", cnt); return TSTA_ERR_INTERNAL; }
         if (one_copy) {
