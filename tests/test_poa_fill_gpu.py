@@ -372,3 +372,46 @@ def test_reference_undefined_warnings(eng):
     steps, end_col, _ = eng.poa_align(*args)
     assert eng.last_status == 0
     assert ([(int(t["node"]), int(t["col"]), int(t["code"]), int(t["peek"])) for t in steps], end_col) == (want_steps, want_end)
+
+
+def _walk_tuple(steps):
+    return [(int(s["node"]), int(s["col"]), int(s["code"]), int(s["peek"])) for s in steps]
+
+
+@pytest.mark.parametrize("step", [1, 2, 3, 4])
+def test_walk_through_the_block_table_readme_graphs(eng, step):
+    """K4t (poa_fill.hip): the POA walk crossing its column blocks by table look-up returns the steps of the step-by-step walk, on the
+    four graphs of the README example (5 000 columns, 5 000 - 10 130 nodes), and the table is really in use."""
+    z = np.load(os.path.join(util.GOLDEN_DIR, "poa_readme_step%d.npz" % step))
+    args = (z["pred_off"], z["pred"], z["base"], z["is_sink"], z["seq"])
+    try:
+        eng.set_option("walk_table", 0)
+        want, want_end, last0 = eng.poa_align(*args)
+        assert eng.stat("last_walk_jumps") == 0
+        eng.set_option("walk_table", 1)
+        got, got_end, last1 = eng.poa_align(*args)
+        jumps = eng.stat("last_walk_jumps")
+    finally:
+        eng.set_option("walk_table", 1)
+    assert got_end == want_end and np.array_equal(last0, last1)
+    assert _walk_tuple(got) == _walk_tuple(want)
+    assert jumps >= 0.8 * (len(z["seq"]) // 32 - 1), jumps
+    if step == 4:                                            # ... and both equal the Python restatement of node_fuse's walk over the arrays
+        best, last, src, es, fs = eng.poa_fill(*args)
+        ref, ref_end = util.poa_walk(z["pred_off"], z["pred"], z["is_sink"], last, src, es, fs)
+        assert (_walk_tuple(got), got_end) == (ref, ref_end)
+
+
+def test_walk_through_the_block_table_random_dags(eng):
+    """graphs whose walks leave the corridor, end inside a block, start away from the last node: every block the table cannot serve is
+    walked step by step, the result is the same"""
+    try:
+        for seed, V, mp, n in [(21, 1200, 4, 700), (22, 3000, 6, 1500), (23, 5000, 3, 300), (24, 1500, 12, 2600), (25, 2048, 2, 96)]:
+            pred_off, pred, base, is_sink, seq = random_dag(seed, V, mp, n)
+            eng.set_option("walk_table", 0)
+            want, want_end, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
+            eng.set_option("walk_table", 2)
+            got, got_end, _ = eng.poa_align(pred_off, pred, base, is_sink, seq)
+            assert (_walk_tuple(got), got_end) == (_walk_tuple(want), want_end), (seed, V, mp, n)
+    finally:
+        eng.set_option("walk_table", 1)

@@ -437,6 +437,11 @@ struct PoaWalkArgs {
     tsta_poa_step* steps;                // out, capacity V + n + 2
     int* out;                            // out[0] = number of steps (-1: the walk was refused / ran into inconsistent trace arrays), out[1] = end column, out[2] = start node
     const unsigned* status;              // status word of the single-launch fill before it (null: none): non-zero = the arrays are not to be trusted
+    // K4t (below): the walk crosses blocks of kPoaCB columns through a table
+    unsigned* tab;                       // [nbnd + 1][Wn][2]: boundary b = 2 .. nbnd (column b kPoaCB - 1), entry node lo[b] + idx, forced = -1 / 126; null: none
+    int* tlo;                            // [nbnd + 1]: first node of boundary b's corridor (written by poa_walk_origin_kernel)
+    int* seg;                            // [2 (nbnd + 1)]: seg[2b] = (entry node + 1) | (forced == 126) << 31 of a block crossed by look-up (0: not), seg[2b+1] = steps before it
+    int Wn, nbnd;                        // corridor width in nodes (multiple of 256), boundaries
 };
 
 constexpr int kWalkRows = 128;           // rows of the walker's window (the graph has ~2 nodes per column: rows run out first)
@@ -449,12 +454,129 @@ __device__ __forceinline__ void wlane(int& v, int val, int idx)
 typedef __attribute__((address_space(3))) const int8_t LdsI8;
 typedef __attribute__((address_space(1))) const int8_t GlobalI8;
 
+// ---- K4t (round 4): the POA walk crosses blocks of columns through a table --------------------------------------------------
+// As K3t of psa_trace.hip: what the walk does between the moment it reaches column c_b = b kPoaCB - 1 and the moment it reaches
+// c_b - kPoaCB depends only on the node and the state (forced = -1, or 126: in the middle of an insertion) it arrives with.
+// poa_walk_origin_kernel computes that for every node of a corridor around the straight line from the last node to the first,
+// every boundary and both states, one thread per entry: {nodes moved, steps, state at the exit}.  The walker crosses a block with
+// one look-up (slices of 16 boundaries staged in LDS at a time), noting where it entered; poa_walk_emit_kernel walks every noted
+// block again, one thread per block, and writes its steps at the offset the walker counted.  A missing entry (outside the
+// corridor, a walk that ends inside the block, wanders for more than 100 steps or meets a byte the fill cannot have written) is
+// a block the walker crosses step by step as before: the result does not depend on the table.
+constexpr int kPoaCB = 32;
+// entry: bits 0-9 steps (at most 100), 10-21 nodes moved, 22 forced == 126 at the exit, 31 valid
+
+__device__ __forceinline__ int sext3(int v) { return (int)((unsigned)v << 29) >> 29; }
+
+// one step of the walk (c-t-simd.c:753-956 as poa_walk_kernel below takes it), per lane, from memory.  Everything the step may need
+// of its own cell — source byte, first predecessors, E and F bytes, the F byte to the left — is asked for at once (global loads,
+// one round trip; only an E step's look at its predecessor's row is a second one).  false: the arrays are not what a fill writes
+// (the caller gives up).  wants_peek: a diagonal step whose predecessor cell exists — its "peek" is the source byte of the cell the
+// walk is at afterwards.  sb_out: the cell's own source byte (the peek of the step before).
+__device__ __forceinline__ bool poa_lane_step(const PoaWalkArgs& A, int& num1, int& num2, int& forced, int& sb_out, int& code_out, bool& wants_peek)
+{
+    typedef __attribute__((address_space(1))) const int8_t G8;
+    typedef __attribute__((address_space(1))) const int G32;
+    typedef int i32x4_w __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const i32x4_w G128;
+    const size_t cell = (size_t)num1 * A.tpitch + num2;
+    const int sb = *(G8*)(A.source + cell);
+    const i32x4_w pt = *(G128*)(A.ptab + num1);
+    const int es = *(G8*)(A.esource + cell);
+    const int fb = *(G8*)(A.fsource + cell);
+    const int fl = num2 >= 1 ? (int)*(G8*)(A.fsource + cell - 1) : 0;
+    sb_out = sb;
+    const int code = forced >= 0 ? forced : sb;
+    forced = -1;
+    wants_peek = false;
+    code_out = code;
+    if (code < 0) return false;
+    const int kind = code / 42, pidx = code % 42;
+    int psub = -1;
+    if (kind != 3) {
+        if (pidx < 4) psub = pidx == 0 ? pt.x : (pidx == 1 ? pt.y : (pidx == 2 ? pt.z : pt.w));
+        else { const int po = *(G32*)(A.pred_off + num1); if (pidx < *(G32*)(A.pred_off + num1 + 1) - po) psub = *(G32*)(A.pred + po + pidx); }
+        if (psub < -1 || psub >= num1) return false;
+    }
+    if (kind == 3) {                                       // F (:753-772); the F code is the low 3 bits
+        const int fs = sext3(fb), afs = fs < 0 ? -fs : fs;
+        if (num2 - 1 > 0 && (afs == 1 || (afs == 2 && sext3(fl) < 0))) forced = 126;
+        num2 -= 1;
+    } else if (kind == 0) {                                // E (:773-785)
+        if (psub > 0) {
+            const int esp = *(G8*)(A.esource + (size_t)psub * A.tpitch + num2);
+            if ((es <= 42 && es >= -42) || ((es > 42 || es < -42) && esp < 0)) { const int s5 = esp % 42; forced = (s5 < 0 ? -s5 : s5) - 1; }
+        }
+        num1 = psub;
+    } else {                                               // match / mismatch (:786-860, :861-956)
+        wants_peek = psub >= 0 && num2 - 1 >= 0;
+        num1 = psub; num2 -= 1;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void poa_walk_origin_kernel(PoaWalkArgs A)
+{
+    const int b = (int)blockIdx.y + 2;
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= 2 * A.Wn) return;
+    const int idx = x >> 1, fi = x & 1;
+    const int c = b * kPoaCB - 1, stop = c - kPoaCB;
+    const int centre = (int)((long long)(A.V - 1) * (c + 1) / A.n);
+    const int lo = max(0, min(centre - A.Wn / 2, A.V - A.Wn));
+    if (x == 0) A.tlo[b] = lo;
+    int num1 = lo + idx, num2 = c, forced = fi ? 126 : -1, cnt = 0;
+    const int node0 = num1;
+    bool ok = true;
+    while (num2 > stop) {
+        // (a block of the real walk takes kPoaCB steps plus its gaps; a walk started far off the path may skip nodes by the hundred:
+        // no walk that matters is that long, and the kernel ends when its last thread does: its time is this cap x ~1 us per step)
+        if (num1 < 0 || cnt >= 100) { ok = false; break; }
+        int sb, code; bool wp;
+        if (!poa_lane_step(A, num1, num2, forced, sb, code, wp)) { ok = false; break; }
+        ++cnt;
+    }
+    unsigned out = 0u;
+    if (ok && num1 >= 0 && node0 - num1 <= 4095 && (forced == -1 || forced == 126))
+        out = (unsigned)cnt | ((unsigned)(node0 - num1) << 10) | (forced == 126 ? 1u << 22 : 0u) | 0x80000000u;
+    A.tab[((size_t)b * A.Wn + idx) * 2 + fi] = out;
+}
+
+__global__ __launch_bounds__(64) void poa_walk_emit_kernel(PoaWalkArgs A)
+{
+    const int b = (int)(blockIdx.x * 64 + threadIdx.x) + 2;
+    if (b > A.nbnd) return;
+    const int sv = A.seg[2 * b];
+    if (sv == 0) return;
+    int num1 = (sv & 0x7fffffff) - 1, num2 = b * kPoaCB - 1, forced = sv < 0 ? 126 : -1, ns = A.seg[2 * b + 1];
+    const int stop = num2 - kPoaCB;
+    bool pending = false;
+    tsta_poa_step prec = {0, 0, 0, 0, 0};
+    while (num2 > stop && num1 >= 0) {
+        tsta_poa_step st; st.node = num1; st.col = num2; st.peek = 0; st.pad = 0;
+        int sb, code; bool wp;
+        const bool fine = poa_lane_step(A, num1, num2, forced, sb, code, wp);
+        if (pending) { prec.peek = (int8_t)(((unsigned)(sb - 42) < 42u) ? 1 : 0); A.steps[ns++] = prec; pending = false; }
+        if (!fine) break;                                    // (cannot happen: the origin walk took the same steps)
+        st.code = (int8_t)code;
+        if (wp) { prec = st; pending = true; } else A.steps[ns++] = st;
+    }
+    if (pending) {
+        const int sb = (num1 >= 0 && num2 >= 0) ? (int)A.source[(size_t)num1 * A.tpitch + num2] : 0;
+        prec.peek = (int8_t)(((unsigned)(sb - 42) < 42u) ? 1 : 0);
+        A.steps[ns++] = prec;
+    }
+}
+
 // LINKS: the fill left, above the 3 bits of every F code, the distance to the predecessor the cell's own move goes to
 // (PoaArgs::links): a step is then one LDS round — the cell's source and fsource bytes — and the "peek" of a diagonal step is
 // the source byte the NEXT step reads anyway.
-template <bool LINKS>
+// TAB: with the block table of K4t (a separate instantiation: its slices cost LDS and registers the plain walker does without)
+template <bool LINKS, bool TAB = false>
 __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
 {
+    static_assert(!TAB || LINKS, "the table walk is built on the linked arrays");
+    __shared__ uint4 ttab[TAB ? 16 * 128 : 1];  // TAB: 16 boundaries x 256 entry nodes x 2 states
     __shared__ uint4 win[3][kWalkRows][4];      // [array][row][64 bytes]
     __shared__ int wpo[kWalkRows], wnp[kWalkRows], wpred[kWalkRows][4];   // predecessor lists of the window's rows (first 4 of each)
     __shared__ int wbb[kWalkRows];       // bit j: predecessor j of the row is the row just above it
@@ -463,7 +585,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     // fill's status word is set; on the way, every step must move to a smaller node or a smaller column and every code must
     // be one the fill can have written — then ns <= V + n (the capacity of steps[]) and every read stays inside the arrays.
     // A violation ends the walk with out[0] = -1.
-    if (A.status != nullptr && __builtin_amdgcn_readfirstlane((int)*A.status) != 0) { if (lane == 0) { A.out[0] = -1; A.out[1] = A.n - 1; } return; }
+    if (A.status != nullptr && __builtin_amdgcn_readfirstlane((int)*A.status) != 0) { if (lane == 0) { A.out[0] = -1; A.out[1] = A.n - 1; A.out[3] = 0; } return; }
     bool bad = false;
     // start: best sink among sort indices >= 1 (max lastsorce, lowest index on ties), else the last node (:737-750)
     int bv = INT_MIN, bi = -1;
@@ -478,7 +600,13 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     int num2 = A.n - 1, forced = -1, ns = 0;
     if (lane == 0) A.out[2] = num1;
     bool pend = false; int pend_node = 0, pend_col = 0, pend_code = 0, pend_idx = 0;     // LINKS: diagonal step waiting for its peek
-    bool try_probe = true;                                     // LINKS: the walk is in a stretch of backbone cells (distance-1 links)
+    bool try_probe = !TAB;                                     // LINKS: the walk is in a stretch of backbone cells (distance-1 links)
+    int tried_b = 0, jumps = 0;                                // TAB: boundary at which a look-up has failed (not tried again there)
+    // TAB: is the walk at a block boundary, in a state the table knows, where no look-up has failed yet?
+    auto at_boundary = [&]() -> bool {
+        const int bq = (num2 + 1) / kPoaCB;
+        return ((num2 + 1) & (kPoaCB - 1)) == 0 && (forced == -1 || forced == 126) && bq >= 2 && bq <= A.nbnd && bq != tried_b;
+    };
     LdsI8* wb = (LdsI8*)reinterpret_cast<const int8_t*>(win);
 
     // A window in registers: what one lane holds of it (rows lane and 64 + lane), and how it is loaded / put into LDS.  The
@@ -525,6 +653,64 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
     int nxt_rw0 = -1, nxt_cw0 = -1;
 
     while (num1 >= 0 && num2 >= 0) {
+        if constexpr (TAB) {
+            if (at_boundary()) {
+                const int b0 = (num2 + 1) / kPoaCB;
+                tried_b = b0;
+                const int lo_l = A.tlo[max(2, b0 - (lane & 15))];                          // lane k: first corridor node of boundary b0 - k
+                if ((unsigned)(num1 - __builtin_amdgcn_readfirstlane(lo_l)) < (unsigned)A.Wn) {
+                    if (pend) {                                    // the step before was a diagonal move to this cell: its peek
+                        const int sbp = __builtin_amdgcn_readfirstlane((int)*(GlobalI8*)(A.source + (size_t)num1 * A.tpitch + num2));
+                        if (lane == 0) {
+                            tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code;
+                            st.peek = (int8_t)(((unsigned)(sbp - 42) < 42u) ? 1 : 0); st.pad = 0;
+                            A.steps[pend_idx] = st;
+                        }
+                        pend = false;
+                    }
+                    // ---- slices of this and the next 15 boundaries, 256 entry nodes around the straight line through (num1, num2), into
+                    // LDS; then up to 16 blocks are crossed by look-up
+                    const int npb = (int)((long long)(A.V - 1) * kPoaCB / A.n);          // nodes per block along that line
+                    const unsigned* tw = reinterpret_cast<const unsigned*>(ttab);
+                    typedef __attribute__((address_space(1))) const u32x4_w GlobalU4W;
+                    int ws[16], los[16];
+                    u32x4_w tmp[32];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int bb = max(2, b0 - k);
+                        los[k] = __builtin_amdgcn_readlane(lo_l, k);
+                        ws[k] = max(0, min(num1 - k * npb - 128 - los[k], A.Wn - 256)) & ~1;
+                        GlobalU4W* src = (GlobalU4W*)(A.tab + ((size_t)bb * A.Wn + ws[k]) * 2);
+                        tmp[2 * k] = src[lane]; tmp[2 * k + 1] = src[64 + lane];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        ttab[k * 128 + lane] = make_uint4(tmp[2 * k].x, tmp[2 * k].y, tmp[2 * k].z, tmp[2 * k].w);
+                        ttab[k * 128 + 64 + lane] = make_uint4(tmp[2 * k + 1].x, tmp[2 * k + 1].y, tmp[2 * k + 1].z, tmp[2 * k + 1].w);
+                    }
+                    __syncthreads();
+                    int jumped = 0;
+                    bool go = true;                               // (no break: the loop unrolls, ws[] stays in registers)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int bb = b0 - k;
+                        const int idx = num1 - los[k] - ws[k];
+                        go = go && bb >= 2 && num1 >= 0 && (forced == -1 || forced == 126) && (unsigned)idx < 256u;
+                        unsigned en = 0u;
+                        if (go) en = (unsigned)__builtin_amdgcn_readfirstlane((int)tw[(k * 256 + idx) * 2 + (forced == 126 ? 1 : 0)]);
+                        go = go && (en >> 31) != 0u;
+                        if (go) {
+                            if (lane == 0) { A.seg[2 * bb] = (num1 + 1) | (forced == 126 ? (int)0x80000000 : 0); A.seg[2 * bb + 1] = ns; }
+                            ns += (int)(en & 1023u); num1 -= (int)((en >> 10) & 4095u); forced = ((en >> 22) & 1u) ? 126 : -1; num2 -= kPoaCB;
+                            ++jumped;
+                        }
+                    }
+                    __syncthreads();
+                    jumps += jumped;
+                    if (jumped) { tried_b = 0; continue; }
+                }
+            }
+        }
         // stage the window whose lower-right region holds (num1, num2): the predicted one if the walk arrived inside it with room
         // to go on, else a fresh one
         int rw0, cw0;
@@ -565,6 +751,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
             if (__builtin_expect(num1 < 0 || num2 < 0, 0)) break;
             int wi = num1 - rw0, wc = num2 - cw0;
             if (__builtin_expect((unsigned)wi >= (unsigned)kWalkRows || (unsigned)wc >= 64u, 0)) break;                 // restage
+            if constexpr (TAB) { if (at_boundary()) break; }      // back to the table
             if constexpr (LINKS) {
                 if (__builtin_expect(forced < 0 && try_probe, 0)) {          // (laid out of line: where it runs, a probe takes up to 64 cells)
                     // ---- a run of backbone cells (diagonal moves to the row just above: link distance 1) is taken at once: lane l
@@ -621,10 +808,10 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
                         num1 -= d; num2 -= 1; a -= d * 64 + 1;
                         ones = (d == 1) ? ones + 1 : 0;
                         if (__builtin_expect(num2 < 0, 0)) { why = 2; break; }
-                        if (__builtin_expect(num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8, 0)) { why = 1; break; }
+                        if (__builtin_expect(num1 < rw0 || num2 < cw0 || k == 64 || ones >= 8 || (TAB && ((num2 + 1) & (kPoaCB - 1)) == 0), 0)) { why = 1; break; }
                     }
                     ns += k - k0;
-                    if (why == 1 && ones >= 8) try_probe = true;                                    // a backbone stretch: probe it
+                    if (!TAB && why == 1 && ones >= 8) try_probe = true;                            // a backbone stretch: probe it
                     if (why == 0) wlane(rec, sb & 0xff, k);      // (k <= 63 here) the cell the chain stopped at: the last step's peek
                     const int code_l = rec & 0xff, d_l = rec >> 8;
                     int pre = d_l;                               // inclusive prefix sum of the distances over the lanes (DPP, VALU only)
@@ -782,7 +969,7 @@ __global__ __launch_bounds__(64) void poa_walk_kernel(PoaWalkArgs A)
         tsta_poa_step st; st.node = pend_node; st.col = pend_col; st.code = (int8_t)pend_code; st.peek = 0; st.pad = 0;
         A.steps[pend_idx] = st;
     }
-    if (lane == 0) { A.out[0] = bad ? -1 : ns; A.out[1] = num2; }
+    if (lane == 0) { A.out[0] = bad ? -1 : ns; A.out[1] = num2; A.out[3] = jumps; }
 }
 
 }  // namespace tsta
@@ -1148,8 +1335,26 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
     Wk.steps = reinterpret_cast<tsta_poa_step*>(e->in_seqs.p);
     Wk.out = A.best + 4;
     Wk.status = e->poa_status;                              // (dataflow fill: the walker does not start on arrays of an abandoned launch)
-    if (A.links) hipLaunchKernelGGL(poa_walk_kernel<true>, dim3(1), dim3(64), 0, s, Wk);
+    Wk.tab = nullptr; Wk.tlo = nullptr; Wk.seg = nullptr; Wk.Wn = 0; Wk.nbnd = 0;
+    // a long sequence against a large graph: the walk crosses its column blocks through a table (K4t); worth its three launches from
+    // a few dozen blocks up
+    const int nbnd = n / kPoaCB, Wn = 1024;
+    if (A.links && e->opt_walk_table != 0 && V >= Wn && ((e->opt_walk_table == 1 && nbnd >= 48) || (e->opt_walk_table == 2 && nbnd >= 2))) {
+        const size_t tab_b = ((size_t)(nbnd + 1) * Wn * 2 * sizeof(unsigned) + 255) / 256 * 256, seg_b = ((size_t)2 * (nbnd + 1) * sizeof(int) + 255) / 256 * 256;
+        if (e->reserve(e->walk_tab, tab_b + seg_b + (size_t)(nbnd + 1) * sizeof(int) + 256, "hipMalloc(walk table)") == TSTA_OK) {
+            Wk.tab = reinterpret_cast<unsigned*>(e->walk_tab.p); Wk.Wn = Wn; Wk.nbnd = nbnd;
+            Wk.seg = reinterpret_cast<int*>(reinterpret_cast<char*>(e->walk_tab.p) + tab_b);
+            Wk.tlo = reinterpret_cast<int*>(reinterpret_cast<char*>(e->walk_tab.p) + tab_b + seg_b);
+            if ((rc = e->check(hipMemsetAsync(Wk.seg, 0, seg_b, s), "hipMemsetAsync(walk segments)"))) return rc;
+            // (the origin walks read the arrays of a fill that may have been abandoned: they stay inside the arrays whatever the bytes)
+            hipLaunchKernelGGL(poa_walk_origin_kernel, dim3((unsigned)((2 * Wn + 255) / 256), (unsigned)(nbnd - 1)), dim3(256), 0, s, Wk);
+            e->n_launches += 1;
+        } else e->err[0] = '\0';
+    }
+    if (Wk.tab) hipLaunchKernelGGL((poa_walk_kernel<true, true>), dim3(1), dim3(64), 0, s, Wk);
+    else if (A.links) hipLaunchKernelGGL(poa_walk_kernel<true>, dim3(1), dim3(64), 0, s, Wk);
     else hipLaunchKernelGGL(poa_walk_kernel<false>, dim3(1), dim3(64), 0, s, Wk);
+    if (Wk.tab) { hipLaunchKernelGGL(poa_walk_emit_kernel, dim3((unsigned)((nbnd + 62) / 64)), dim3(64), 0, s, Wk); e->n_launches += 1; }
     e->n_launches += 1;
     e->timing_end(s);
     if ((rc = e->check(hipGetLastError(), "poa_walk launch"))) return rc;
@@ -1160,6 +1365,7 @@ static int poa_align_once(tsta_engine* eng, const tsta_params* p, const tsta_dag
         return rc;
     if ((rc = poa_dataflow_status(e)) != TSTA_OK) return rc;
     const int ns = h_out[0];
+    e->last_walk_jumps = h_out[3];
     if (ns < 0 || (size_t)ns > cap) { e->set_error("walker returned %d steps", ns); return TSTA_ERR_INTERNAL; }
     tsta_poa_step* out = (tsta_poa_step*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(tsta_poa_step));
     if (!out) return TSTA_ERR_OOM;

@@ -649,7 +649,7 @@ typedef __attribute__((address_space(1))) uint8_t GlobalU8;
 // crosses a band with one table look-up (slices of 32 boundaries staged in LDS at a time, around the diagonal through the current
 // cell), noting where it entered; psa_walk_emit_kernel walks every noted band again, one thread per band, and writes its ops at the
 // offset the walker counted.  Exactness does not depend on the table: an entry that is missing (outside the corridor, a walk
-// that ends inside the band or wanders for more than 1 000 steps) is simply a band the walker crosses step by step as before.
+// that ends inside the band or wanders for more than 512 steps) is simply a band the walker crosses step by step as before.
 struct WalkTabArgs {
     unsigned* tab;       // [nb + 1][Wc]: boundary b = 1 .. nb (row i = b BAND), entry column lo(b) + idx, entered free (forced = -1); null: no table
     int Wc, nb;          // corridor width in columns (multiple of 256), boundaries
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void psa_walk_origin_kernel(const TraceJob* jo
         const int64_t band_bytes = J.band_bytes;
         auto byte = [&](int ci, int cj) -> unsigned { return trace_byte_at<R>(trace, band_bytes, ci, cj); };
         while (i > stop) {
-            if (j < 1 || cnt >= 1000) { ok = false; break; }
+            if (j < 1 || cnt >= 512) { ok = false; break; }
             walk_one_step(byte, i, j, forced);
             ++cnt;
         }
