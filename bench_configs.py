@@ -216,12 +216,15 @@ def config3(eng, cores=None, verify=True, cpu=True):
     assert (ms, ra, rb) == (ms2, ra2, rb2)
     k2, wall2 = float(np.median(ks)), float(np.median(walls))
     form = eng.stat("last_trace_form")                     # what actually ran (the label below is derived from it)
+    jumps = eng.stat("last_walk_jumps")                    # bands the walk crossed through its table (K3t)
+    walk = ("psa_walk_origin_kernel + psa_walk_kernel<2,32,true> + psa_walk_emit_kernel (%d of %d bands by table look-up)" % (jumps, (len(y) - 1) // 128)
+            if jumps else "psa_walk_kernel<2,32,false>")
     cells = float(len(x)) * len(y)
     out = {"config": "#3: one %d x %d pair with traceback (1 B/cell packed trace in HBM: %.1f GB)" % (len(x), len(y), cells / 1e9),
            "maxsorce": ms, "alignment_len": len(ra), "kernel_ms_first": k1, "kernel_ms": k2, "launches": nl,
            "wall_ms_first": wall1 * 1e3, "wall_ms": wall2, "gcups": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e6,
-           "reruns": eng.stat("single_launch_reruns"), "trace_form": form,
-           "roofline": _trace_roofline(cells, k2, TRACE_FORMS.get(form, "form %d" % form) + " + psa_walk_kernel<2,32>",
+           "reruns": eng.stat("single_launch_reruns"), "trace_form": form, "walk_table_jumps": jumps,
+           "roofline": _trace_roofline(cells, k2, TRACE_FORMS.get(form, "form %d" % form) + " + " + walk,
                                        "psa_trace_split_kernel" if form in (3, 4) else None)}
     if out["reruns"]:
         out["flag"] = "a single launch was abandoned and run again through the launch pipeline: kernel_ms is not the single-launch form's"
@@ -291,6 +294,7 @@ def config4(eng, cores=None, verify=True, cpu=True):
         tot_cells += cells; tot_fill += k_fill; tot_fw += k_fw; tot_wall += wall; rows += V
         ok = ok and (V, int(last[best])) == README_LASTSORCE[step - 1]
         steps.append({"step": step, "nodes": V, "fill_kernel_ms": k_fill, "fill_plus_walk_kernel_ms": k_fw, "fill_plus_walk_wall_ms": wall,
+                      "walk_table_jumps": eng.stat("last_walk_jumps"),
                       "walk_steps": int(len(st)), "best_lastsorce": int(last[best]), "us_per_row": k_fill * 1e3 / V})
     byts = 11.0 * tot_cells                                  # 3 B trace codes + 8 B H / Eagg row per cell
     out = {"config": "#4: TSTA_msa README example (5 x 5 kbp): 4 POA fills + on-device walks", "steps": steps,
@@ -369,7 +373,7 @@ def config5t(eng, cores=None, n_pairs=64, L=50_000, verify=True, cpu=True):
     out = {"config": "#5 shape with traceback: %d pairs of %d x ~%d in one group (%.0f GB of packed trace in HBM)" % (n_pairs, L, L, cells / 1e9),
            "kernel_ms_first": k1, "kernel_ms": k2, "launches": nl, "wall_ms_first_with_allocation": wall1 * 1e3, "wall_ms": wall2,
            "gcups": cells / k2 / 1e6, "gcups_wall": cells / wall2 / 1e6, "reruns": eng.stat("single_launch_reruns"),
-           "roofline": _trace_roofline(cells, k2, "psa_trace_packed_tile_kernel<4,true> + psa_walk_kernel<4,32>", "psa_trace_packed_tile_kernel")}
+           "roofline": _trace_roofline(cells, k2, "psa_trace_packed_tile_kernel<4,true> + psa_walk_kernel<4,32,false>", "psa_trace_packed_tile_kernel")}
     if verify:
         for (ms, ra, rb), (a, b) in zip(res, pairs):
             la, lb = (a, b) if len(a) >= len(b) else (b, a)

@@ -34,6 +34,7 @@ echo "config traffic done"
   echo "==== tests/tools/wave_log.py (P=8192)"; timeout -k 10 200 python tests/tools/wave_log.py 2>&1 | grep -v "amdgpu.ids\|\[tsta\]"
   echo "==== tests/tools/wave_log.py (P=4096)"; P=4096 timeout -k 10 200 python tests/tools/wave_log.py 2>&1 | grep -v "amdgpu.ids\|\[tsta\]"
   echo "==== tests/tools/mixed_alphabet_timing.py"; timeout -k 10 200 python tests/tools/mixed_alphabet_timing.py 2>&1 | grep -v amdgpu.ids
+  echo "==== tests/tools/walk_table_timing.py"; timeout -k 10 200 python tests/tools/walk_table_timing.py 2>&1 | grep -v amdgpu.ids
 } > $O/side_timings.txt 2>&1
 ./tools/cell_microbench > $O/cell_microbench.txt 2>&1 || true
 echo "side timings done"

@@ -188,6 +188,7 @@ int tsta_engine_create(int device, tsta_engine** out)
     if (const char* v = getenv("TSTA_PSA_BANDS")) e->opt_psa_bands = atoi(v);
     if (const char* v = getenv("TSTA_PSA_PERM")) e->opt_psa_perm = atoi(v) != 0;
     if (const char* v = getenv("TSTA_PSA_F16MAX")) e->opt_psa_f16max = std::max(0, std::min(4, atoi(v)));
+    if (const char* v = getenv("TSTA_WALK_TABLE")) e->opt_walk_table = std::max(0, std::min(2, atoi(v)));
     if (const char* v = getenv("TSTA_PSA_R")) e->opt_psa_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_R")) e->opt_trace_rows = atoi(v);
     if (const char* v = getenv("TSTA_TRACE_T")) e->opt_trace_tile = atoi(v);
