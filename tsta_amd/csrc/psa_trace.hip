@@ -64,7 +64,10 @@ struct TLane {
 // ACGT (split form, pure-ACGT pairs): the match / mismatch term is ONE v_bfe_i32 instead of compare + select — s.bch[k] holds the
 // row's four substitution scores as bytes (score against A, C, T, G at byte (ASCII >> 1) & 3), the column character travels as
 // 8 x that code, i.e. as the bit offset of its byte.  One instruction less per cell on the chain of dependent steps.
-template <int R, bool PRED, bool TRACE, bool FULL = false, bool ACGT = false>   // FULL: every row of the band is a real row (no mask on the running max)
+// LEAN (solvers of the split form, steady blocks): no running maximum — the emitter tiles, which compute every cell again off the
+// chain, keep it — and no copy of the last row's H into hl[R-1] (nothing reads it inside a block: the caller sets it from hbot at
+// the block's end).  Two instructions less on the chain of dependent steps.
+template <int R, bool PRED, bool TRACE, bool FULL = false, bool ACGT = false, bool LEAN = false>   // FULL: every row of the band is a real row (no mask on the running max)
 __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int lane, const int n, const int nvalid,
                                            const int M, const int X, const int E, const int O, int (&tb)[(R + 3) / 4])
 {
@@ -102,10 +105,10 @@ __device__ __forceinline__ void trace_step(TLane<R>& s, const int t, const int l
             s.fb[k] = act ? fbn : s.fb[k];
             hv = act ? hv : kNegInfT;
         } else {
-            s.hl[k] = h;
+            if (!(LEAN && k == R - 1)) s.hl[k] = h;
             s.fb[k] = fbn;
         }
-        s.mx = max(s.mx, hv);
+        if (!LEAN) s.mx = max(s.mx, hv);
         eu = eb;
     }
     s.hbot = h;
@@ -172,7 +175,7 @@ __device__ __forceinline__ void lds_wait_ge(int* word, int need, unsigned* statu
 
 constexpr int kLinkG = 16;                                // columns per LDS hand-off (16 / R steps make one trace group: G is a multiple of it)
 
-template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true, bool ACGT = false>
+template <int R, bool PRED, bool FULL, bool LTOP, bool LBOT, bool TRACE = true, bool ACGT = false, bool LEAN = false>
 __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, const int lane, const int n, const int nvalid,
                                                    const int M, const int X, const int E, const int O, uint4* __restrict__ tq,
                                                    const LdsLink& L, const int S_total, unsigned* status,
@@ -181,8 +184,8 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
     constexpr int SPB = TraceCfg<R>::SPB;
     constexpr int G = kLinkG > SPB ? kLinkG : SPB;
     static_assert(G % SPB == 0 && 64 % G == 0, "hand-off every G steps");
-#pragma unroll 1
-    for (int g = 0; g < 64 / SPB; ++g) {
+    __builtin_assume((t0 & 63) == 0);
+    auto group = [&](const int g) {
         const int ts = t0 + g * SPB;
         // a band that takes its top row from memory: the progress word of the band above is looked at HALF A BLOCK before the
         // next block needs it (one sc1 load in flight behind the steps; the block's start then finds the answer in a register
@@ -204,12 +207,13 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
             int tb[(R + 3) / 4];
 #pragma unroll
             for (int x = 0; x < (R + 3) / 4; ++x) tb[x] = 0;
-            trace_step<R, PRED, TRACE, FULL, ACGT>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
+            trace_step<R, PRED, TRACE, FULL, ACGT, LEAN>(s, ts + q, lane, n, nvalid, M, X, E, O, tb);
             if constexpr (!TRACE) { (void)acc; }
             else if constexpr (R == 8) { acc[2 * q] = tb[0]; acc[2 * q + 1] = tb[1]; }
             else if constexpr (R == 4) { acc[q] = tb[0]; }
             else { acc[(q * R) / 4] = (tb[0] << (8 * ((q * R) % 4))) + acc[(q * R) / 4]; }
         }
+        if constexpr (LEAN) s.hl[R - 1] = s.hbot;              // (what the steps above did not keep; once per group, off the steps)
         if constexpr (TRACE)
             tq[(size_t)g * 64] = make_uint4((unsigned)acc[0] + 0x14141414u, (unsigned)acc[1] + 0x14141414u,
                                             (unsigned)acc[2] + 0x14141414u, (unsigned)acc[3] + 0x14141414u);
@@ -224,6 +228,15 @@ __device__ __forceinline__ void trace_block_linked(TLane<R>& s, const int t0, co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) __hip_atomic_store(L.done_mine, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    };
+    if constexpr (LEAN && G == 2 * SPB) {
+        // the solvers' steady blocks: a hand-off period (two groups) per iteration (four: no faster) — the tests of "is this a hand-off step" fold away
+        // and the loop's own instructions, which a lone wave pays like any other, are halved
+#pragma unroll 1
+        for (int g = 0; g < 64 / SPB; g += 2) { group(g); group(g + 1); }
+    } else {
+#pragma unroll 1
+        for (int g = 0; g < 64 / SPB; ++g) group(g);
     }
 }
 
@@ -315,10 +328,11 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
         const int* poll = (!top_lds && w > 0) ? &A.progress[g - 1] : nullptr;
 #define TSTA_LINKED(PRED_, FULL_)                                                                                                        \
         do {                                                                                                                             \
-            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
-            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
-            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above);  \
-            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE, ACGT>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above); \
+            constexpr bool LEAN_ = SPLIT && !(PRED_);          /* steady solver blocks: see trace_step */                                \
+            if (top_lds && bot_lds)  trace_block_linked<R, PRED_, FULL_, true, true, TRACE, ACGT, LEAN_>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);   \
+            else if (top_lds)        trace_block_linked<R, PRED_, FULL_, true, false, TRACE, ACGT, LEAN_>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status);  \
+            else if (bot_lds)        trace_block_linked<R, PRED_, FULL_, false, true, TRACE, ACGT, LEAN_>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above);  \
+            else                     trace_block_linked<R, PRED_, FULL_, false, false, TRACE, ACGT, LEAN_>(s, t0, lane, n, nvalid, M, X, E, O, tq, L, S_total, A.status, poll, &seen_above); \
         } while (0)
         if (steady && full) TSTA_LINKED(false, true);
         else if (steady)    TSTA_LINKED(false, false);
@@ -350,7 +364,9 @@ __device__ __forceinline__ void quad_band(const PsaTraceArgs& A, const int wg, c
 #pragma unroll
     for (int k = 0; k < R; ++k) { st[(2 * k) * 64] = s.hl[k]; st[(2 * k + 1) * 64] = s.fb[k]; }
     st[(2 * R) * 64] = s.hd; st[(2 * R + 1) * 64] = s.hbot; st[(2 * R + 2) * 64] = s.ebot;
-    st[(2 * R + 3) * 64] = s.cch; st[(2 * R + 4) * 64] = s.mx;
+    st[(2 * R + 3) * 64] = s.cch;
+    if (SPLIT) atomicMax(&st[(2 * R + 4) * 64], s.mx);        // (the maxima of the steady blocks come from the emitter tiles; the slot was set to -inf before the launch)
+    else st[(2 * R + 4) * 64] = s.mx;
 }
 
 template <int R>
@@ -368,8 +384,10 @@ __global__ __launch_bounds__(256) void psa_trace_quad_kernel(PsaTraceArgs A)
 
 // emitter tiles of the split form are numbered along the diagonals u = w + c K (tile (band w, chunk c) becomes available ~when the
 // tiles of diagonal u do): diag_first[u] = number of tiles on the diagonals before u, diag_first[n_diag] = all of them
-__global__ __launch_bounds__(256) void psa_split_diag_kernel(int* diag_first, int n_diag, int W, int NC, int K)
+__global__ __launch_bounds__(256) void psa_split_diag_kernel(int* diag_first, int n_diag, int W, int NC, int K, int* state, int NS, int mx_slot)
 {
+    // (and the bands' running-maximum slots start at -inf: solvers and emitter tiles fold their maxima in with atomicMax)
+    for (int x = threadIdx.x; x < W * 64; x += 256) state[(size_t)(x / 64) * NS * 64 + mx_slot * 64 + x % 64] = kNegInfT;
     __shared__ int part[257];
     auto count = [&](int u) { const int c_lo = max(0, (u - (W - 1) + K - 1) / K), c_hi = min(NC - 1, u / K); return max(0, c_hi - c_lo + 1); };
     const int per = (n_diag + 255) / 256, u0 = (int)threadIdx.x * per, u1 = min(n_diag, u0 + per);
@@ -437,6 +455,7 @@ __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTrace
         if (s0 > 0) wait_progress(&A.eprog[g], s0, A.status, lane);                            // the band's checkpoint at s0
         if (w > 0)  wait_progress(&A.eprog[g - 1], min(s1 + 64, S_total), A.status, lane);     // the upper band's bottom row, 64 steps further
         const int i0 = w * 64 * R + lane * R;
+        const bool fullband = (w + 1) * 64 * R <= J.m;
         TLane<R> s;
 #pragma unroll
         for (int k = 0; k < R; ++k) s.bch[k] = (i0 + k < J.m) ? (int)seq_b[i0 + k] : 0x100;
@@ -472,10 +491,14 @@ __global__ __launch_bounds__(kSplitThreads) void psa_trace_split_kernel(PsaTrace
             }
             s.th = nt.x; s.te = nt.y; s.ach = na;
             uint4* tq = reinterpret_cast<uint4*>(tband) + ((size_t)(t0 / SPB) * 64 + lane);
-            // (FULL: the running maximum is the solvers' business — nothing here reads s.mx)
-            if (t0 >= 64 && t0 + 63 < n) trace_block<R, false, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
-            else                         trace_block<R, true, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
+            // (the running maximum of every cell is kept HERE, off the solvers' chain: rows beyond m masked in the last band)
+            const bool steady = t0 >= 64 && t0 + 63 < n;
+            if (steady && fullband) trace_block<R, false, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
+            else if (steady)        trace_block<R, false, true, false, false, ACGT>(s, t0, lane, n, J.m - i0, M, X, E, O, tq);
+            else if (fullband)      trace_block<R, true, true, false, true, ACGT>(s, t0, lane, n, R, M, X, E, O, tq);
+            else                    trace_block<R, true, true, false, false, ACGT>(s, t0, lane, n, J.m - i0, M, X, E, O, tq);
         }
+        atomicMax(&J.state[(size_t)w * NS * 64 + (2 * R + 4) * 64 + lane], s.mx);
     }
 }
 
@@ -1217,7 +1240,7 @@ static int run_group(Engine* e, const tsta_params* p, HostJob* jobs, int n_jobs,
             if ((size_t)n_diag + 1 > split_tab_ints) return TSTA_ERR_INTERNAL;
             int* d_eprog = d_sync + 64 + single_bands + couple_bands;                       // cleared by the memset above
             int* d_diag = d_sync + 2 * single_bands + couple_bands + 128 + 2 * d_bound;     // behind the couples' tile table
-            hipLaunchKernelGGL(psa_split_diag_kernel, dim3(1), dim3(256), 0, s, d_diag, n_diag, J0.W, NC, kSplitK);
+            hipLaunchKernelGGL(psa_split_diag_kernel, dim3(1), dim3(256), 0, s, d_diag, n_diag, J0.W, NC, kSplitK, J0.state, TraceCfg<R>::NS, 2 * R + 4);
             ++launches;
             A.eprog = d_eprog; A.ckpt = reinterpret_cast<int*>(e->ckpt.p); A.C = kSplitC; A.NC = NC; A.K = kSplitK;
             A.n_solver_wg = (int)((single_bands + 3) / 4);
